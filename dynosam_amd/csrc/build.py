@@ -1,0 +1,40 @@
+"""Build libdynogfx.so (the C-ABI library of include/dynogfx.h) for gfx950, in-tree."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = ["dynogfx.hip"]
+DEPS = ["dynogfx.hip", "kernels.h", "dev_factors.h", "dev_se3.h", os.path.join("..", "..", "include", "dynogfx.h")]
+OUT = os.path.join(HERE, "libdynogfx.so")
+
+
+def hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    return "hipcc"
+
+
+def stale() -> bool:
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    return any(os.path.getmtime(os.path.join(HERE, d)) > t for d in DEPS)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not stale():
+        return OUT
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics",
+           *[os.path.join(HERE, s) for s in SRC], "-o", OUT]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd, cwd=HERE)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

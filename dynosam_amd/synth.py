@@ -1,0 +1,387 @@
+"""Synthetic dynamic-SLAM scenario → flat HYBRID-formulation factor graph.
+
+A seeded re-statement of the SEMANTICS of the reference's world simulator
+(dynosam/test/internal/simulator.hpp:228-250 constant-motion bodies,
+ :413-466 static point generators, :359-410 object points,
+ simulator.cc:42-203 RGBDScenario::getOutput, :216-271 noise models) feeding the graph shape
+the HYBRID formulation builds (dynosam/src/backend/rgbd/HybridEstimator.cc:573-811,
+Formulation-impl.hpp:145-235, VisionImuBackendModule.hpp:88-243) — SURVEY.md §8(d):
+
+  per frame k   : X_k, BetweenFactor(X_{k-1},X_k) odometry, PriorFactor on X_0 (sigma 1e-6)
+  per object j  : eH_k for every frame it is seen, PriorFactor(Identity, 1e-6) at its keyframe e,
+                  HybridSmoothingFactor(H_{k-2},H_{k-1},H_k; L_e)
+  static tracks : l_i, one PoseToPointFactor(X_k, l_i) per observation
+  dynamic tracks: m_i (object frame, key m(cantor(tracklet,0))), one HybridMotionFactor(X_k,H_k,m_i; L_e)
+
+It is host-side input plumbing for bench.py and the tests (numpy only); nothing here runs in
+the timed region.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import symbols as S
+from .graph import (F_BETWEEN_POSE3, F_HYBRID_MOTION, F_HYBRID_SMOOTHING, F_POSE_TO_POINT, F_PRIOR_POSE3,
+                    VAR_POINT3, VAR_POSE3, FactorBlock, FlatGraph)
+
+# ------------------------------------------------------------------------------------------
+# batched SE(3) helpers (numpy).  pose = (R [...,3,3], t [...,3]).  GTSAM conventions:
+# xi = [omega, v], retract(T, xi) = T * Expmap(xi).
+# ------------------------------------------------------------------------------------------
+
+
+def skew(w):
+    w = np.asarray(w, dtype=np.float64)
+    z = np.zeros(w.shape[:-1])
+    return np.stack([np.stack([z, -w[..., 2], w[..., 1]], -1),
+                     np.stack([w[..., 2], z, -w[..., 0]], -1),
+                     np.stack([-w[..., 1], w[..., 0], z], -1)], -2)
+
+
+def so3_exp(w):
+    w = np.asarray(w, dtype=np.float64)
+    th2 = np.sum(w * w, -1)
+    W = skew(w)
+    WW = W @ W
+    small = th2 <= np.finfo(np.float64).eps
+    th2s = np.where(small, 1.0, th2)
+    th = np.sqrt(th2s)
+    a = np.where(small, 1.0, np.sin(th) / th)
+    b = np.where(small, 0.5, 2.0 * np.sin(th / 2) ** 2 / th2s)
+    return np.eye(3) + a[..., None, None] * W + b[..., None, None] * WW
+
+
+def so3_log(R):
+    R = np.asarray(R, dtype=np.float64)
+    tr = np.trace(R, axis1=-2, axis2=-1)
+    v = np.stack([R[..., 2, 1] - R[..., 1, 2], R[..., 0, 2] - R[..., 2, 0], R[..., 1, 0] - R[..., 0, 1]], -1)
+    tr3 = tr - 3.0
+    c = np.clip((tr - 1.0) / 2.0, -1.0, 1.0)
+    th = np.arccos(c)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        mag = np.where(tr3 < -1e-6, th / (2.0 * np.sin(th)), 0.5 - tr3 / 12.0 + tr3 * tr3 / 60.0)
+    return mag[..., None] * v
+
+
+def se3_exp(xi):
+    xi = np.asarray(xi, dtype=np.float64)
+    w, v = xi[..., :3], xi[..., 3:]
+    R = so3_exp(w)
+    th2 = np.sum(w * w, -1)
+    small = th2 <= np.finfo(np.float64).eps
+    th2s = np.where(small, 1.0, th2)
+    wxv = np.cross(w, v)
+    tpar = w * np.sum(w * v, -1, keepdims=True)
+    t = (wxv - np.einsum("...ij,...j->...i", R, wxv) + tpar) / th2s[..., None]
+    t = np.where(small[..., None], v, t)
+    return R, t
+
+
+def se3_log(R, t):
+    w = so3_log(R)
+    th = np.linalg.norm(w, axis=-1)
+    small = th < 1e-10
+    ths = np.where(small, 1.0, th)
+    W = skew(w / ths[..., None])
+    Wt = np.einsum("...ij,...j->...i", W, t)
+    WWt = np.einsum("...ij,...j->...i", W, Wt)
+    u = t - (0.5 * ths)[..., None] * Wt + (1.0 - ths / (2.0 * np.tan(0.5 * ths)))[..., None] * WWt
+    u = np.where(small[..., None], t, u)
+    return np.concatenate([w, u], -1)
+
+
+def compose(a, b):
+    return a[0] @ b[0], np.einsum("...ij,...j->...i", a[0], b[1]) + a[1]
+
+
+def inverse(a):
+    Rt = np.swapaxes(a[0], -1, -2)
+    return Rt, -np.einsum("...ij,...j->...i", Rt, a[1])
+
+
+def act(a, p):
+    return np.einsum("...ij,...j->...i", a[0], p) + a[1]
+
+
+def to12(a):
+    R, t = a
+    return np.concatenate([R.reshape(R.shape[:-2] + (9,)), t], -1)
+
+
+def from12(s):
+    s = np.asarray(s, dtype=np.float64)
+    return s[..., :9].reshape(s.shape[:-1] + (3, 3)), s[..., 9:12]
+
+
+def rzryrx(x, y, z):
+    """gtsam::Rot3::RzRyRx(x, y, z) = Rz(z) Ry(y) Rx(x)."""
+    cx, sx, cy, sy, cz, sz = np.cos(x), np.sin(x), np.cos(y), np.sin(y), np.cos(z), np.sin(z)
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    return Rz @ Ry @ Rx
+
+
+def ypr(y, p, r):
+    """gtsam::Rot3::Ypr(y, p, r) = RzRyRx(r, p, y)."""
+    return rzryrx(r, p, y)
+
+
+# ------------------------------------------------------------------------------------------
+
+
+@dataclass
+class ScenarioConfig:
+    frames: int = 50
+    objects: int = 1
+    static_points: int = 400
+    dynamic_points_per_object: int = 100
+    static_track: tuple = (6, 14)
+    dynamic_track: tuple = (5, 13)
+    object_lifetime: int = 0          # 0 = alive for the whole sequence; else staggered windows
+    seed: int = 1
+    robust: bool = True
+    k_huber: float = 1e-4             # BackendParams.hpp:92-93
+    static_sigma_xy: float = 0.01     # simulator.cc:250-271 (x depth, x depth^2)
+    static_sigma_z: float = 0.01
+    dynamic_sigma: float = 0.05
+    odom_sigma_rot: float = 0.01
+    odom_sigma_trans: float = 0.05
+    motion_init_sigma_rot: float = 0.02
+    motion_init_sigma_trans: float = 0.1
+    smoothing_sigma_rot: float = 0.01  # BackendParams.cc:33-36
+    smoothing_sigma_trans: float = 0.1
+    prior_sigma: float = 1e-6          # BackendDefinitions.cc:137-138
+    noise_scale: float = 1.0           # 0 → noiseless measurements and ground-truth init
+
+
+def config(n: int, **kw) -> ScenarioConfig:
+    """BASELINE.json configs as concrete synthetic inputs."""
+    base = {
+        1: dict(frames=50, objects=1, static_points=400, dynamic_points_per_object=100, seed=1),
+        2: dict(frames=200, objects=5, static_points=8000, dynamic_points_per_object=400, seed=2),
+        3: dict(frames=24, objects=5, static_points=960, dynamic_points_per_object=48, seed=3),
+        5: dict(frames=2000, objects=50, static_points=160000, dynamic_points_per_object=800,
+                object_lifetime=200, seed=5),
+    }[n]
+    base.update(kw)
+    return ScenarioConfig(**base)
+
+
+def _perturb(rng, pose, s_rot, s_trans):
+    n = pose[1].shape[0]
+    xi = np.concatenate([rng.normal(0, 1, (n, 3)) * s_rot, rng.normal(0, 1, (n, 3)) * s_trans], -1)
+    return compose(pose, se3_exp(xi))
+
+
+def make_hybrid_graph(cfg: ScenarioConfig) -> FlatGraph:
+    rng = np.random.default_rng(cfg.seed)
+    K, J = cfg.frames, cfg.objects
+    ns = cfg.noise_scale
+    frames = np.arange(K)
+
+    # ---- ground truth trajectories (ConstantMotionBodyVisitor: pose_k = Expmap(k Logmap(M)) pose_0)
+    cam_motion = (rzryrx(0.003, 0.002, 0.0)[None], np.array([[0.014, 0.038, 0.0]]))
+    xi_cam = se3_log(*cam_motion)[0]
+    X_gt = se3_exp(frames[:, None] * xi_cam[None])  # pose_0 = identity
+
+    # ---- objects
+    if cfg.object_lifetime and cfg.object_lifetime < K:
+        life = cfg.object_lifetime
+        starts = np.round(np.linspace(0, K - life, J)).astype(int)
+        obj_start, obj_end = starts, starts + life  # [start, end)
+    else:
+        obj_start, obj_end = np.zeros(J, int), np.full(J, K)
+    obj_xi = np.concatenate([rng.normal(0, 0.01, (J, 3)), rng.normal(0, 0.15, (J, 3))], -1)
+    ang = rng.uniform(-0.6, 0.6, J)
+    rad = rng.uniform(5.0, 30.0, J)
+    L0_R = so3_exp(rng.normal(0, 0.3, (J, 3)))
+    L0_t = np.stack([rad * np.sin(ang), rng.uniform(-1, 1, J), rad * np.cos(ang)], -1)
+
+    def obj_pose(j, k):  # k: array of frames (absolute)
+        M = se3_exp((k - obj_start[j])[:, None] * obj_xi[j][None])
+        Xs = (X_gt[0][obj_start[j]], X_gt[1][obj_start[j]])
+        base = compose((Xs[0][None], Xs[1][None]), (L0_R[j][None], L0_t[j][None]))  # placed in front of the camera at birth
+        return compose(M, (np.repeat(base[0], len(k), 0), np.repeat(base[1], len(k), 0)))
+
+    # ---- variable tables -------------------------------------------------------------------
+    keys, vtype, state = [], [], []
+
+    # odometry (VO) : noisy relative poses, used both as BetweenFactor measurement and to build the initial guess
+    rel_gt = compose(inverse((X_gt[0][:-1], X_gt[1][:-1])), (X_gt[0][1:], X_gt[1][1:]))
+    rel_meas = _perturb(rng, rel_gt, cfg.odom_sigma_rot * ns, cfg.odom_sigma_trans * ns)
+    X_init_R, X_init_t = [X_gt[0][0]], [X_gt[1][0]]
+    for k in range(1, K):
+        R = X_init_R[-1] @ rel_meas[0][k - 1]
+        t = X_init_R[-1] @ rel_meas[1][k - 1] + X_init_t[-1]
+        X_init_R.append(R)
+        X_init_t.append(t)
+    X_init = (np.stack(X_init_R), np.stack(X_init_t))
+
+    # ---- object motion variables eH_k = L_k L_e^-1 ; L_e (keyframe pose, constant in the factors)
+    H_keys, H_init12, H_obj, H_frame = [], [], [], []
+    L_e12 = np.zeros((J, 12))
+    H_gt = {}
+    for j in range(J):
+        ks = np.arange(obj_start[j], obj_end[j])
+        Lk = obj_pose(j, ks)
+        Le_gt = (Lk[0][:1], Lk[1][:1])
+        Le = _perturb(rng, Le_gt, 0.05 * ns, 0.2 * ns)  # estimated keyframe pose handed over by the frontend
+        L_e12[j] = to12(Le)[0]
+        Hg = compose(Lk, inverse((np.repeat(Le_gt[0], len(ks), 0), np.repeat(Le_gt[1], len(ks), 0))))
+        H_gt[j] = Hg
+        Hi = _perturb(rng, Hg, cfg.motion_init_sigma_rot * ns, cfg.motion_init_sigma_trans * ns)
+        Hi = (Hi[0].copy(), Hi[1].copy())
+        Hi[0][0] = np.eye(3)  # keyframe motion is initialised (and prior-ed) at identity
+        Hi[1][0] = 0.0
+        H_keys += [S.ObjectMotionSymbol(j + 1, int(k)) for k in ks]
+        H_init12.append(to12(Hi))
+        H_obj += [j] * len(ks)
+        H_frame += list(ks)
+    H_init12 = np.concatenate(H_init12, 0)
+    H_obj = np.array(H_obj)
+    H_frame = np.array(H_frame)
+
+    # ---- static tracks ---------------------------------------------------------------------
+    Ns = cfg.static_points
+    s_len = rng.integers(cfg.static_track[0], cfg.static_track[1] + 1, Ns)
+    s_birth = rng.integers(0, max(1, K - cfg.static_track[0] + 1), Ns)
+    s_len = np.minimum(s_len, K - s_birth)
+    # sampled in the frustum of the camera at the track's mid frame so it stays in view
+    depth = rng.uniform(2.0, 45.0, Ns)
+    uv = np.stack([rng.uniform(-0.55, 0.55, Ns), rng.uniform(-0.4, 0.4, Ns)], -1)
+    p_cam = np.concatenate([uv * depth[:, None], depth[:, None]], -1)
+    mid = np.minimum(s_birth + s_len // 2, K - 1)
+    l_gt = act((X_gt[0][mid], X_gt[1][mid]), p_cam)
+    so_track = np.repeat(np.arange(Ns), s_len)
+    so_frame = np.concatenate([np.arange(b, b + n) for b, n in zip(s_birth, s_len)]) if Ns else np.zeros(0, int)
+    z_gt = act(inverse((X_gt[0][so_frame], X_gt[1][so_frame])), l_gt[so_track])
+    zc = np.maximum(np.abs(z_gt[:, 2]), 0.5)
+    s_sig = np.stack([cfg.static_sigma_xy * zc, cfg.static_sigma_xy * zc, cfg.static_sigma_z * zc * zc], -1)
+    z_s = z_gt + rng.normal(0, 1, z_gt.shape) * s_sig * ns
+    first_obs = np.concatenate([[0], np.cumsum(s_len)[:-1]]) if Ns else np.zeros(0, int)
+    l_init = act((X_init[0][s_birth], X_init[1][s_birth]), z_s[first_obs])  # Formulation-impl.hpp:218-229
+
+    # ---- dynamic tracks --------------------------------------------------------------------
+    Nd_per = cfg.dynamic_points_per_object
+    d_obj = np.repeat(np.arange(J), Nd_per)
+    Nd = len(d_obj)
+    d_len = rng.integers(cfg.dynamic_track[0], cfg.dynamic_track[1] + 1, Nd)
+    span = (obj_end - obj_start)[d_obj]
+    d_birth = obj_start[d_obj] + (rng.uniform(0, 1, Nd) * np.maximum(1, span - cfg.dynamic_track[0] + 1)).astype(int)
+    d_len = np.minimum(d_len, obj_end[d_obj] - d_birth)
+    m_obj_gt = rng.normal(0, 0.5, (Nd, 3))  # in the (ground-truth) object frame
+    do_track = np.repeat(np.arange(Nd), d_len)
+    do_frame = np.concatenate([np.arange(b, b + n) for b, n in zip(d_birth, d_len)]) if Nd else np.zeros(0, int)
+    do_obj = d_obj[do_track]
+    # world point = L_k m ; measured in camera
+    zd_gt = np.zeros((len(do_track), 3))
+    Hidx_of = {}
+    off = 0
+    for j in range(J):
+        n = obj_end[j] - obj_start[j]
+        Hidx_of[j] = off
+        off += n
+    for j in range(J):
+        sel = np.nonzero(do_obj == j)[0]
+        if not len(sel):
+            continue
+        Lk = obj_pose(j, do_frame[sel])
+        pw = act(Lk, m_obj_gt[do_track[sel]])
+        zd_gt[sel] = act(inverse((X_gt[0][do_frame[sel]], X_gt[1][do_frame[sel]])), pw)
+    z_d = zd_gt + rng.normal(0, cfg.dynamic_sigma, zd_gt.shape) * ns
+    d_first = np.concatenate([[0], np.cumsum(d_len)[:-1]]) if Nd else np.zeros(0, int)
+    # init: projectToObject3(X_init, H_init, L_e, z) = L_e^-1 H^-1 X z   (HybridEstimator.cc:647-657)
+    hrow = np.array([Hidx_of[j] for j in d_obj]) + (d_birth - obj_start[d_obj])
+    Hi0 = from12(H_init12[hrow])
+    Le_all = from12(L_e12[d_obj])
+    pw0 = act((X_init[0][d_birth], X_init[1][d_birth]), z_d[d_first])
+    m_init = act(inverse(Le_all), act(inverse(Hi0), pw0))
+
+    # ---- assemble variables in ascending key order -------------------------------------------
+    X_keys = [S.CameraPoseSymbol(int(k)) for k in range(K)]
+    l_keys = [S.StaticLandmarkSymbol(int(i)) for i in range(Ns)]
+    m_keys = [S.HybridDynamicKey(int(Ns + i)) for i in range(Nd)]
+    all_keys = np.array(H_keys + X_keys + l_keys + m_keys, dtype=np.uint64)
+    all_type = np.array([VAR_POSE3] * (len(H_keys) + K) + [VAR_POINT3] * (Ns + Nd), dtype=np.uint8)
+    pad = lambda p: np.concatenate([p, np.zeros((len(p), 9))], -1)
+    all_state = np.concatenate([H_init12, to12(X_init), pad(l_init), pad(m_init)], 0)
+    order = np.argsort(all_keys, kind="stable")
+    var_keys, var_type, var_state = all_keys[order], all_type[order], all_state[order]
+    inv = np.empty_like(order)
+    inv[order] = np.arange(len(order))
+    nH = len(H_keys)
+    Hvar = inv[np.arange(nH)]
+    Xvar = inv[nH + np.arange(K)]
+    lvar = inv[nH + K + np.arange(Ns)]
+    mvar = inv[nH + K + Ns + np.arange(Nd)]
+
+    # ---- ground truth in the same layout (for tests) ------------------------------------------
+    Hgt12 = np.concatenate([to12(H_gt[j]) for j in range(J)], 0)
+    # dynamic points in the L_e frame actually used by the factors: m = L_e^-1 Le_gt m_gt
+    LeGt = {j: inverse((H_gt[j][0][:1], H_gt[j][1][:1])) for j in range(J)}
+    Le_gt12 = []
+    for j in range(J):
+        Lk0 = obj_pose(j, np.array([obj_start[j]]))
+        Le_gt12.append(to12(Lk0)[0])
+    Le_gt_all = from12(np.array(Le_gt12)[d_obj])
+    m_gt = act(inverse(Le_all), act(Le_gt_all, m_obj_gt))
+    gt_state = np.concatenate([Hgt12, to12(X_gt), pad(l_gt), pad(m_gt)], 0)[order]
+    # NOTE: with L_e != L_e_gt the ground-truth object motion in the factor's convention is
+    # H = L_k L_e_gt^-1 (world frame), independent of L_e; m absorbs the offset. Exact zero residual.
+
+    # ---- factors (slot = insertion order, frame-major like the per-frame formulation update) ---
+    # slot ordering key: (frame, class rank, index)
+    recs = []  # (frame, rank, local index) per factor, concatenated over blocks in block order
+    blocks = []
+
+    def iso6(sr, st, n):
+        return np.tile(np.array([sr] * 3 + [st] * 3), (n, 1))
+
+    # priors: X_0 and each object's keyframe motion
+    pr_var = [Xvar[0]] + [Hvar[Hidx_of[j]] for j in range(J)]
+    pr_meas = np.concatenate([to12((X_gt[0][:1], X_gt[1][:1])), np.tile(to12((np.eye(3)[None], np.zeros((1, 3)))), (J, 1))], 0)
+    pr_frame = np.array([0] + [obj_start[j] for j in range(J)])
+    blocks.append((F_PRIOR_POSE3, np.array(pr_var)[:, None], pr_meas, iso6(cfg.prior_sigma, cfg.prior_sigma, J + 1), None, None, pr_frame, 0))
+    # odometry
+    bt_var = np.stack([Xvar[:-1], Xvar[1:]], -1)
+    blocks.append((F_BETWEEN_POSE3, bt_var, to12(rel_meas), iso6(cfg.odom_sigma_rot, cfg.odom_sigma_trans, K - 1), None, None, np.arange(1, K), 1))
+    # static observations
+    Rs = np.zeros((len(so_track), 9))
+    Rs[:, 0], Rs[:, 4], Rs[:, 8] = 1.0 / s_sig[:, 0], 1.0 / s_sig[:, 1], 1.0 / s_sig[:, 2]
+    hk_s = np.full(len(so_track), cfg.k_huber) if cfg.robust else None
+    blocks.append((F_POSE_TO_POINT, np.stack([Xvar[so_frame], lvar[so_track]], -1), z_s, Rs, hk_s, None, so_frame, 2))
+    # dynamic observations
+    hrow_o = np.array([Hidx_of[j] for j in do_obj], dtype=int) + (do_frame - obj_start[do_obj]) if len(do_obj) else np.zeros(0, int)
+    Rd = np.zeros((len(do_track), 9))
+    Rd[:, 0] = Rd[:, 4] = Rd[:, 8] = 1.0 / cfg.dynamic_sigma
+    hk_d = np.full(len(do_track), cfg.k_huber) if cfg.robust else None
+    blocks.append((F_HYBRID_MOTION, np.stack([Xvar[do_frame], Hvar[hrow_o], mvar[do_track]], -1), z_d, Rd, hk_d, L_e12[do_obj], do_frame, 3))
+    # smoothing
+    sm_var, sm_c, sm_f = [], [], []
+    for j in range(J):
+        n = obj_end[j] - obj_start[j]
+        for i in range(2, n):
+            b = Hidx_of[j]
+            sm_var.append([Hvar[b + i - 2], Hvar[b + i - 1], Hvar[b + i]])
+            sm_c.append(L_e12[j])
+            sm_f.append(obj_start[j] + i)
+    if sm_var:
+        blocks.append((F_HYBRID_SMOOTHING, np.array(sm_var), np.zeros((len(sm_var), 0)), iso6(cfg.smoothing_sigma_rot, cfg.smoothing_sigma_trans, len(sm_var)), None, np.array(sm_c), np.array(sm_f), 4))
+
+    # slots
+    tot = sum(len(b[1]) for b in blocks)
+    fr = np.concatenate([b[6] for b in blocks])
+    rk = np.concatenate([np.full(len(b[1]), b[7]) for b in blocks])
+    ordr = np.lexsort((np.arange(tot), rk, fr))
+    slot_of = np.empty(tot, dtype=np.int32)
+    slot_of[ordr] = np.arange(tot, dtype=np.int32)
+    out_blocks, o = [], 0
+    for (t, var, meas, noise, hk, cst, _f, _r) in blocks:
+        n = len(var)
+        out_blocks.append(FactorBlock(t, slot_of[o:o + n], var, meas, noise, hk, cst))
+        o += n
+    meta = dict(cfg=cfg, gt_state=gt_state, n_static=Ns, n_dynamic=Nd, frames=K, objects=J)
+    return FlatGraph(var_keys, var_type, var_state, out_blocks, meta)

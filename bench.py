@@ -1,0 +1,173 @@
+#!/usr/bin/env python
+"""bench.py — LM iterations/sec on the synthetic 100k-factor dynamic-SLAM graph (BASELINE.json).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is ONE Levenberg-Marquardt outer iteration (GTSAM's iterate(): linearise once, then
+tryLambda until accepted or exhausted) of the hot path on BASELINE config 2, starting from the
+same initial values; K steps = the first K outer iterations of the solve (values already
+resident in HBM; the graph is uploaded before the timed region).
+
+Weak scaling: N GPUs solve an N-times longer trajectory (N x 200 frames, N x ~98k factors),
+factors sharded by keyframe window, reduced system summed with one all-reduce per linear solve
+(torch.distributed NCCL == RCCL).  `value` = LM iterations/s x (total factors / 100k-graph
+factors), i.e. "100k-factor-graph LM iterations per second" aggregated over the job, so that
+value(N)/(N value(1)) is the weak-scaling efficiency.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP64_PEAK_TFLOPS = 78.6   # MI355X fp64 vector/matrix peak
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from dynosam_amd import synth
+    from dynosam_amd.optimizer import Context, LevenbergMarquardtParams
+
+    cfg = synth.config(args.config)
+    base_factors = None
+    if world > 1:  # weak scaling: N x longer trajectory, same per-frame density
+        g1 = synth.make_hybrid_graph(cfg)
+        base_factors = g1.n_factors
+        cfg = synth.config(args.config, frames=cfg.frames * world, static_points=cfg.static_points * world,
+                           dynamic_points_per_object=cfg.dynamic_points_per_object * world)
+    g = synth.make_hybrid_graph(cfg)
+    if base_factors is None:
+        base_factors = g.n_factors
+    shard = g.shard(rank, world)
+
+    stream = torch.cuda.Stream()
+
+    def allreduce(ptr, count):
+        # wrap the device buffer without copying; RCCL all-reduce on the solver's stream
+        buf = torch.empty(0, dtype=torch.float64, device="cuda")
+        storage = torch._C._construct_storage_from_data_pointer(ptr, torch.device("cuda", local_rank), count * 8)
+        buf.set_(storage, 0, (count,))
+        with torch.cuda.stream(stream):
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        stream.synchronize()
+
+    ctx = Context(device=local_rank, world_size=world, rank=rank, allreduce=allreduce if world > 1 else None,
+                  stream=stream.cuda_stream)
+    ctx.upload(shard)
+
+    def run(n_iter):
+        ctx.set_values(g.var_state)
+        P = LevenbergMarquardtParams()
+        P.max_iterations = n_iter
+        P.relative_error_tol = 0.0   # time EXACTLY n_iter outer iterations (no early convergence exit)
+        P.absolute_error_tol = -1.0
+        return ctx.optimize(P)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.warmup:
+        run(args.warmup)
+    ctx.reset_kernel_stats()
+    sync()
+    t0 = time.perf_counter()
+    rep = run(args.steps)
+    sync()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    steps_done = int(rep.iterations)
+    stats = ctx.kernel_stats()
+
+    out = None
+    if rank == 0:
+        scale = g.n_factors / base_factors
+        value = steps_done / dt * scale
+        # dominant kernel = largest total time in the timed region (HIP events on the solver stream)
+        dom = max(stats, key=lambda s: s["total_ms"])
+        avg_s = dom["total_ms"] * 1e-3 / max(1, dom["launches"])
+        if dom["name"] == "k_chol_step":
+            roof = dict(bound="mfma", kernel=dom["name"], achieved=dom["algorithmic_flops"] / avg_s / 1e12,
+                        peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", traffic=None, avg_launch_us=avg_s * 1e6,
+                        launches=dom["launches"])
+        else:
+            roof = dict(bound="hbm", kernel=dom["name"], achieved=dom["algorithmic_bytes"] / avg_s / 1e9,
+                        peak=HBM_PEAK_GBS, unit="GB/s", traffic=None, avg_launch_us=avg_s * 1e6, launches=dom["launches"])
+        roof["frac"] = roof["achieved"] / roof["peak"]
+        out = {
+            "metric": "LM iters/sec on 100k-factor graph", "value": value, "unit": "LM outer iterations/s (x total_factors/100k-graph factors)",
+            "n_gpus": world, "steps": steps_done, "warmup": args.warmup, "ms_per_step": 1e3 * dt / max(1, steps_done),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"BASELINE config {args.config}: synthetic {cfg.frames} frames, {cfg.objects} objects, "
+                                   f"{cfg.static_points + cfg.objects * cfg.dynamic_points_per_object} landmarks, HYBRID formulation, "
+                                   f"{g.n_factors} factors, {g.n_vars} variables, Huber k=1e-4, GTSAM-default LM",
+                       "factors": g.n_factors, "variables": g.n_vars, "inner_iterations": int(rep.inner_iterations),
+                       "error_before": rep.error_before, "error_after": rep.error_after, "sharding": f"keyframe-window x{world}"},
+            "roofline": roof,
+            "kernels": [{"name": s["name"], "launches": s["launches"], "total_ms": round(s["total_ms"], 3)} for s in stats],
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(g, base_factors)
+        else:
+            out["cpu_baseline"] = None
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+def cpu_baseline(g, base_factors):
+    """The CPU oracle (a port restating GTSAM-4.2.0 LM semantics — NOT the GTSAM binary) timed on
+    this box's host cores on a bounded sample: the first 3 LM outer iterations of the same graph."""
+    from oracle import oracle_py as O
+    from dynosam_amd.optimizer import LevenbergMarquardtParams
+    cores = min(8, len(os.sched_getaffinity(0)))
+    O.set_threads(cores)
+    og = O.OracleGraph(g)
+    P = LevenbergMarquardtParams()
+    P.max_iterations = 3
+    P.relative_error_tol = 0.0
+    P.absolute_error_tol = -1.0
+    t0 = time.perf_counter()
+    r, _ = og.optimize(P)
+    dt = time.perf_counter() - t0
+    return {"value": r.iterations / dt * (g.n_factors / base_factors), "unit": "LM outer iterations/s", "cores": cores,
+            "kind": "port", "sample": f"first {r.iterations} LM outer iterations ({r.inner_iterations} linear solves) of the same "
+            f"{g.n_factors}-factor graph, {dt:.2f} s; CPU oracle (GTSAM-4.2.0 semantics), not the GTSAM binary"}
+
+
+if __name__ == "__main__":
+    main()

@@ -206,15 +206,18 @@ class FlatGraph:
                 sel = vt[:, a] == VAR_POINT3
                 np.minimum.at(first, b.var_idx[sel, a], pose_frames[sel])
         del owner
-        width = (max_frame + 1 + world_size - 1) // world_size
-        out = []
+        # owner frame of every factor: its point's first-observation frame, else its latest pose frame
+        fo = []
         for b in self.blocks:
             vt = self.var_type[b.var_idx]
             has_pt = (vt == VAR_POINT3).any(axis=1)
             pt_first = np.where(vt == VAR_POINT3, first[b.var_idx], np.iinfo(np.int64).max).min(axis=1)
             pose_last = np.where(vt == VAR_POSE3, frame_of_var[b.var_idx], -1).max(axis=1)
-            f = np.where(has_pt, pt_first, pose_last)
-            r = np.minimum(f // width, world_size - 1)
-            out.append(b.subset(r == rank))
+            fo.append(np.where(has_pt, pt_first, pose_last))
+        # contiguous keyframe windows holding ~equal factor counts (a frame never straddles two ranks)
+        hist = np.bincount(np.concatenate(fo), minlength=max_frame + 1).astype(np.float64)
+        before = np.concatenate([[0.0], np.cumsum(hist)[:-1]])
+        rank_of_frame = np.minimum((before * world_size / max(1.0, hist.sum())).astype(np.int64), world_size - 1)
+        out = [b.subset(rank_of_frame[f] == rank) for b, f in zip(self.blocks, fo)]
         g = FlatGraph(self.var_keys, self.var_type, self.var_state, out, dict(self.meta))
         return g

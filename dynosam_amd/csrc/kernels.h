@@ -441,40 +441,78 @@ __device__ __forceinline__ int64_t band_addr(int i, int j, int nbt) {
 }
 
 struct AssembleView {
-  int64_t n_blk;
-  const int32_t* blk_a;
-  const int32_t* blk_b;
-  const int32_t* sp_ptr;   // [n_blk+1] schur pair CSR
-  const int32_t* sp_e;     // [2*npairs]
-  const int32_t* dp_ptr;   // [n_blk+1] direct contribution CSR
+  int64_t n_chunk;
+  const int32_t* ch_kind;  // 0: schur pairs, 1: direct
+  const int32_t* ch_lo;    // first contribution of the chunk (index into sp_e pairs / dp_* arrays)
+  const int32_t* ch_n;     // <= 64
+  const int32_t* sp_e;     // [2*npairs] edge ids
   const int64_t* dp_a;     // offset of A_a (d x 6)
   const int64_t* dp_b;
   const int8_t* dp_d;
+  int64_t n_blk;
+  const int32_t* blk_a;
+  const int32_t* blk_b;
+  const int32_t* blk_ch;   // [n_blk+1] chunks of a block are contiguous
   int nbt;
 };
 
-__global__ __launch_bounds__(256) void k_assemble(AssembleView A, const double* __restrict__ Jbuf, const double* __restrict__ Z,
-                                                  const double* __restrict__ lambda_p, double add_lambda,
-                                                  double* __restrict__ Sb) {
-  const int64_t blk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+// pass 1: one wavefront per chunk of <= 64 contributions to ONE 6x6 block. Lanes first fetch the
+// chunk's indices (one contribution per lane, coalesced), then lanes 0..35 = (i,j) walk the chunk
+// with the indices broadcast by readlane, so the Z / J loads of successive contributions are
+// independent and pipeline.  Fixed order => deterministic.
+__global__ __launch_bounds__(256) void k_assemble_chunks(AssembleView A, const double* __restrict__ Jbuf,
+                                                         const double* __restrict__ Z, double* __restrict__ partial) {
+  const int64_t ch = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  if (blk >= A.n_blk || lane >= 36) return;
-  const int i = lane / 6, j = lane % 6;
+  if (ch >= A.n_chunk) return;
+  const int n = A.ch_n[ch], lo = A.ch_lo[ch];
+  const int i = (lane < 36) ? lane / 6 : 0, j = (lane < 36) ? lane % 6 : 0;
+  double acc = 0;
+  if (A.ch_kind[ch] == 0) {
+    int e1 = 0, e2 = 0;
+    if (lane < n) { e1 = A.sp_e[2 * (lo + lane)]; e2 = A.sp_e[2 * (lo + lane) + 1]; }
+    // 4 contributions per trip: their 24 loads are independent and issue back to back
+    for (int k0 = 0; k0 < n; k0 += 4) {
+      double t[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = k0 + u;   // lanes >= n hold edge 0 (a valid address); masked by w
+        const int f1 = __builtin_amdgcn_readlane(e1, k & 63), f2 = __builtin_amdgcn_readlane(e2, k & 63);
+        const double* z1 = Z + 18 * (int64_t)f1 + 3 * i;
+        const double* z2 = Z + 18 * (int64_t)f2 + 3 * j;
+        t[u] = (k < n) ? z1[0] * z2[0] + z1[1] * z2[1] + z1[2] * z2[2] : 0.0;
+      }
+      acc -= (t[0] + t[1]) + (t[2] + t[3]);
+    }
+  } else {
+    int64_t oa = 0, ob = 0;
+    int d = 0;
+    if (lane < n) { oa = A.dp_a[lo + lane]; ob = A.dp_b[lo + lane]; d = A.dp_d[lo + lane]; }
+#pragma unroll 2
+    for (int k = 0; k < n; ++k) {
+      const int64_t pa = ((int64_t)__builtin_amdgcn_readlane((int)(oa >> 32), k) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)oa, k);
+      const int64_t pb = ((int64_t)__builtin_amdgcn_readlane((int)(ob >> 32), k) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)ob, k);
+      const int dd = __builtin_amdgcn_readlane(d, k);
+      const double* Aa = Jbuf + pa + i;
+      const double* Ab = Jbuf + pb + j;
+      acc += Aa[0] * Ab[0] + Aa[6] * Ab[6] + Aa[12] * Ab[12];
+      if (dd == 6) acc += Aa[18] * Ab[18] + Aa[24] * Ab[24] + Aa[30] * Ab[30];
+    }
+  }
+  if (lane < 36) partial[ch * 36 + lane] = acc;
+}
+
+// pass 2: one lane per (block, element): sum the block's chunk partials in order, add damping, store
+__global__ void k_assemble_final(AssembleView A, const double* __restrict__ partial, const double* __restrict__ lambda_p,
+                                 double add_lambda, double* __restrict__ Sb) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t blk = t / 36;
+  const int el = (int)(t % 36);
+  if (blk >= A.n_blk) return;
+  const int i = el / 6, j = el % 6;
   const int a = A.blk_a[blk], b = A.blk_b[blk];
   double acc = (a == b && i == j) ? add_lambda * (*lambda_p) : 0.0;
-  for (int k = A.dp_ptr[blk]; k < A.dp_ptr[blk + 1]; ++k) {
-    const double* Aa = Jbuf + A.dp_a[k];
-    const double* Ab = Jbuf + A.dp_b[k];
-    const int d = A.dp_d[k];
-    for (int r = 0; r < d; ++r) acc += Aa[r * 6 + i] * Ab[r * 6 + j];
-  }
-  double s = 0;
-  for (int k = A.sp_ptr[blk]; k < A.sp_ptr[blk + 1]; ++k) {
-    const double* z1 = Z + 18 * (int64_t)A.sp_e[2 * k] + 3 * i;
-    const double* z2 = Z + 18 * (int64_t)A.sp_e[2 * k + 1] + 3 * j;
-    s += z1[0] * z2[0] + z1[1] * z2[1] + z1[2] * z2[2];
-  }
-  acc -= s;
+  for (int c = A.blk_ch[blk]; c < A.blk_ch[blk + 1]; ++c) acc += partial[(int64_t)c * 36 + el];
   const int gi = 6 * a + i, gj = 6 * b + j;
   if (gi >= gj) Sb[band_addr(gi, gj, A.nbt)] = acc;
 }
@@ -555,37 +593,64 @@ __device__ __forceinline__ void store_tile(double* __restrict__ g, const double*
   g2[tid + 256] = l2[tid + 256];
 }
 
-// in-LDS Cholesky of a TSxTS tile (column-major, lower). D is overwritten by L (lower incl. diagonal),
-// dinv[k] = 1 / L[k][k].  One barrier per column: the trailing update uses the unscaled column.
-__device__ __forceinline__ void tile_potrf(double* D, double* dsq, double* dinv, int tid, int col0, int* fail_flag) {
+// 1/x to full double precision: v_rcp_f64 seed + two Newton steps (x > 0, finite)
+__device__ __forceinline__ double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+  // Newton: r <- r * (1.5 - 0.5 x r^2), twice
+  r = r * fma(-0.5 * x * r, r, 1.5);
+  r = r * fma(-0.5 * x * r, r, 1.5);
+  return r;
+}
+
+// Cholesky of a TSxTS tile by 256 lanes, register resident: lane (i = tid&31, jg = tid>>5) owns the
+// four elements (i, jg + 8s).  Column k is broadcast through a double-buffered LDS vector, ONE
+// barrier per column; the trailing update uses the unscaled column (a_ij -= a_ik a_jk / a_kk).
+// On exit D holds L (lower, column-major) and dinv[k] = 1 / L[k][k].
+__device__ __forceinline__ void tile_potrf(double* __restrict__ D, double* __restrict__ colbuf /*2*TS*/,
+                                           double* __restrict__ dinv, int tid, int col0, int* fail_flag) {
+  const int i = tid & 31, jg = tid >> 5;
+  double a[4], dd[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) { a[s] = D[i + TS * (jg + 8 * s)]; dd[s] = 1.0; }
+#pragma unroll
   for (int k = 0; k < TS; ++k) {
-    const double akk = D[k + TS * k];
-    const double inv = 1.0 / akk;
-    const int m = TS - 1 - k;
-    for (int idx = tid; idx < m * m; idx += 256) {
-      const int i = k + 1 + idx % m, j = k + 1 + idx / m;
-      if (i >= j) D[i + TS * j] -= D[i + TS * k] * D[j + TS * k] * inv;
-    }
+    if (jg == (k & 7)) colbuf[(k & 1) * TS + i] = a[k >> 3];
     __syncthreads();
+    const double* ck = colbuf + (k & 1) * TS;
+    const double akk = ck[k];
+    if (jg == (k & 7)) dd[k >> 3] = akk;
+    const double lik = ck[i] * fast_rcp(akk);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int j = jg + 8 * s;
+      if (j > k && i >= j) a[s] -= lik * ck[j];
+    }
   }
-  if (tid < TS) {
-    const double akk = D[tid + TS * tid];
-    const bool ok = akk > 0.0;
-    if (!ok) atomicMin(fail_flag, col0 + tid);
-    const double sq = ok ? sqrt(akk) : 1.0;
-    dsq[tid] = sq;
-    dinv[tid] = 1.0 / sq;
-  }
-  __syncthreads();
-  for (int idx = tid; idx < TT; idx += 256) {
-    const int i = idx % TS, k = idx / TS;
-    if (i > k) D[idx] *= dinv[k];
-    else if (i == k) D[idx] = dsq[k];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int j = jg + 8 * s;
+    const bool ok = dd[s] > 0.0;
+    const double rs = ok ? fast_rsqrt(dd[s]) : 1.0;
+    if (i == j) {
+      if (!ok) atomicMin(fail_flag, col0 + j);
+      D[i + TS * j] = ok ? dd[s] * rs : 1.0;
+      dinv[j] = rs;
+    } else if (i > j) {
+      D[i + TS * j] = a[s] * rs;
+    }
   }
   __syncthreads();
 }
 
-// X (TS rows) = A L^-T, one lane per row, row held in registers; L lower in LDS (column-major)
+// X (TS rows) = A L^-T: one lane per row, row held in registers; L (lower) is read from LDS as
+// broadcasts.  Right-looking: once x[c] is known every later column is updated independently, so
+// the FMAs pipeline (no dependent accumulation chain).
 __device__ __forceinline__ void tile_trsm_row(const double* __restrict__ L, const double* __restrict__ dinv,
                                               double* __restrict__ Arow_tile, int r) {
   double x[TS];
@@ -593,10 +658,9 @@ __device__ __forceinline__ void tile_trsm_row(const double* __restrict__ L, cons
   for (int c = 0; c < TS; ++c) x[c] = Arow_tile[r + TS * c];
 #pragma unroll
   for (int c = 0; c < TS; ++c) {
-    double s = x[c];
+    x[c] *= dinv[c];
 #pragma unroll
-    for (int m = 0; m < c; ++m) s -= x[m] * L[c + TS * m];
-    x[c] = s * dinv[c];
+    for (int m = c + 1; m < TS; ++m) x[m] -= x[c] * L[m + TS * c];
   }
 #pragma unroll
   for (int c = 0; c < TS; ++c) Arow_tile[r + TS * c] = x[c];
@@ -607,45 +671,75 @@ __device__ __forceinline__ void tile_trsm_row(const double* __restrict__ L, cons
 // WG of the same launch overwrites.)
 __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ Sb, double* __restrict__ Rb, double* __restrict__ Lb,
                                                    double* __restrict__ Yb, int J, int nt, int nbt,
-                                                   const int2* __restrict__ roles, int* __restrict__ fail_flag) {
+                                                   const int2* __restrict__ roles, int* __restrict__ fail_flag, int dbg_mode) {
   __shared__ __attribute__((aligned(16))) double D[TT];
   __shared__ __attribute__((aligned(16))) double P[TT];
   __shared__ __attribute__((aligned(16))) double Q[TT];
-  __shared__ double dsq[TS], dinv[TS];
+  __shared__ __attribute__((aligned(16))) double colbuf[2 * TS];
+  __shared__ double dinv[TS];
   const int tid = threadIdx.x;
   const int p = roles[blockIdx.x].x, q = roles[blockIdx.x].y;
   const bool p_rhs = (p == nbt + 1);
   if ((!p_rhs && J + p >= nt) || J + q >= nt) return;
   const int64_t colJ = (int64_t)J * (nbt + 1);
-  load_tile(Sb + colJ * TT, D, tid);
-  if (p > 0) load_tile(p_rhs ? Rb + (int64_t)J * TT : Sb + (colJ + p) * TT, P, tid);
-  if (q > 0 && q != p) load_tile(Sb + (colJ + q) * TT, Q, tid);
+  const bool need_q = q > 0 && q != p;
+  // issue every global load up front; the panel tiles land in registers while the diagonal factors
+  const double2* gd = reinterpret_cast<const double2*>(Sb + colJ * TT);
+  const double2* gp = reinterpret_cast<const double2*>(p_rhs ? Rb + (int64_t)J * TT : Sb + (colJ + p) * TT);
+  const double2* gq = reinterpret_cast<const double2*>(Sb + (colJ + q) * TT);
+  const double2 d0 = gd[tid], d1 = gd[tid + 256];
+  double2 p0 = make_double2(0, 0), p1 = p0, q0 = p0, q1 = p0;
+  if (p > 0) { p0 = gp[tid]; p1 = gp[tid + 256]; }
+  if (need_q) { q0 = gq[tid]; q1 = gq[tid + 256]; }
+  // trailing tile prefetch
+  double* tgt = nullptr;
+  const int c = tid >> 3, r0 = (tid & 7) * 4;  // update mapping: 4 consecutive rows of one column
+  double t4[4] = {0, 0, 0, 0};
+  if (q > 0) {
+    tgt = p_rhs ? Rb + (int64_t)(J + q) * TT : Sb + ((int64_t)(J + q) * (nbt + 1) + (p - q)) * TT;
+    const double2* g2 = reinterpret_cast<const double2*>(tgt + r0 + TS * c);
+    const double2 u0 = g2[0], u1 = g2[1];
+    t4[0] = u0.x; t4[1] = u0.y; t4[2] = u1.x; t4[3] = u1.y;
+  }
+  if (dbg_mode == 0) return;
+  reinterpret_cast<double2*>(D)[tid] = d0;
+  reinterpret_cast<double2*>(D)[tid + 256] = d1;
   __syncthreads();
-  tile_potrf(D, dsq, dinv, tid, J * TS, fail_flag);
+  if (dbg_mode == 1) { if (d0.x == 1.2345e-300 && p1.x + q1.x + t4[0] == 7.0) Lb[0] = 0; return; }
+  tile_potrf(D, colbuf, dinv, tid, J * TS, fail_flag);
+  if (dbg_mode == 2) { if (D[tid] == 1.2345e-300) Lb[0] = 0; return; }
   if (p == 0) {
     store_tile(Lb + colJ * TT, D, tid);
     return;
   }
-  if (tid < TS) tile_trsm_row(D, dinv, P, tid);
-  else if (tid >= 64 && tid < 64 + TS && q > 0 && q != p) tile_trsm_row(D, dinv, Q, tid - 64);
+  reinterpret_cast<double2*>(P)[tid] = p0;
+  reinterpret_cast<double2*>(P)[tid + 256] = p1;
+  if (need_q) {
+    reinterpret_cast<double2*>(Q)[tid] = q0;
+    reinterpret_cast<double2*>(Q)[tid + 256] = q1;
+  }
   __syncthreads();
+  if (tid < TS) tile_trsm_row(D, dinv, P, tid);
+  else if (tid >= 64 && tid < 64 + TS && need_q) tile_trsm_row(D, dinv, Q, tid - 64);
+  __syncthreads();
+  if (dbg_mode == 3) { if (P[tid] == 1.2345e-300) Lb[0] = 0; return; }
   if (q == 0) {
     store_tile(p_rhs ? Yb + (int64_t)J * TT : Lb + (colJ + p) * TT, P, tid);
     return;
   }
   // trailing update of tile (J+p, J+q)
   const double* Qt = (q == p) ? P : Q;
-  double* tgt = p_rhs ? Rb + (int64_t)(J + q) * TT : Sb + ((int64_t)(J + q) * (nbt + 1) + (p - q)) * TT;
-  const int c = tid >> 3, r0 = (tid & 7) * 4;  // thread -> 4 consecutive rows of one column
   double acc[4] = {0, 0, 0, 0};
 #pragma unroll 8
   for (int k = 0; k < TS; ++k) {
     const double qv = Qt[c + TS * k];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] += P[r0 + r + TS * k] * qv;
+    const double2 pa = *reinterpret_cast<const double2*>(P + r0 + TS * k);
+    const double2 pb = *reinterpret_cast<const double2*>(P + r0 + 2 + TS * k);
+    acc[0] += pa.x * qv; acc[1] += pa.y * qv; acc[2] += pb.x * qv; acc[3] += pb.y * qv;
   }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) tgt[r0 + r + TS * c] -= acc[r];
+  double2* o2 = reinterpret_cast<double2*>(tgt + r0 + TS * c);
+  o2[0] = make_double2(t4[0] - acc[0], t4[1] - acc[1]);
+  o2[1] = make_double2(t4[2] - acc[2], t4[3] - acc[3]);
 }
 
 // inverse of every diagonal tile's L (lower): Linv tiles, one WG of 64 lanes per tile, lane = column
@@ -672,35 +766,52 @@ __global__ __launch_bounds__(64) void k_tri_inv(const double* __restrict__ Lb, i
 }
 
 // backward substitution L^T x = y (y = row 0 of the Yb tiles), single workgroup of 1024 lanes:
-// lane (r = tid&31, c = tid>>5) owns element (r,c) of every tile of column J.
+// lane (r = tid&31, c = tid>>5) owns element (r,c) of every tile of column J.  The tiles of column
+// J-1 are prefetched into registers while column J is reduced (MAXB tiles per column).
+template <int MAXB>
 __global__ __launch_bounds__(1024) void k_back(const double* __restrict__ Lb, const double* __restrict__ Yb,
                                                const double* __restrict__ Linv, int nt, int nbt, int n,
                                                double* __restrict__ x_out) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
   double* xs = sh;                      // ring: (nbt+1) * TS solved values, slot = J % (nbt+1)
-  double* sv = sh + (nbt + 1) * TS;     // [TS] reduced vector
+  double* sv = sh + (nbt + 1) * TS;     // [2][TS] reduced vector, double buffered
   const int tid = threadIdx.x;
   const int r = tid & 31, c = tid >> 5;
-  for (int J = nt - 1; J >= 0; --J) {
-    double s = 0;
+  double cur[MAXB], nxt[MAXB];
+  double li_cur = 0, li_nxt = 0, y_cur = 0, y_nxt = 0;
+  auto fetch = [&](int J, double* dst, double& li, double& y) {
     const int pmax = (nt - 1 - J) < nbt ? (nt - 1 - J) : nbt;
-    for (int p = 1; p <= pmax; ++p) {
-      const double* T = Lb + ((int64_t)J * (nbt + 1) + p) * TT;
-      s += T[r + TS * c] * xs[((J + p) % (nbt + 1)) * TS + r];
+    const double* base = Lb + ((int64_t)J * (nbt + 1)) * TT + r + TS * c;
+#pragma unroll
+    for (int p = 1; p <= MAXB; ++p) dst[p - 1] = (p <= pmax) ? base[(int64_t)p * TT] : 0.0;
+    li = Linv[(int64_t)J * TT + r + TS * c];   // Linv[r][c]
+    y = Yb[(int64_t)J * TT + TS * c];
+  };
+  fetch(nt - 1, cur, li_cur, y_cur);
+  for (int J = nt - 1; J >= 0; --J) {
+    if (J > 0) fetch(J - 1, nxt, li_nxt, y_nxt);
+    double s = 0;
+#pragma unroll
+    for (int p = 1; p <= MAXB; ++p) {
+      // xs of tiles beyond the matrix are never read because cur[] is zero there
+      const int slot = (J + p) % (nbt + 1);
+      s += cur[p - 1] * ((p <= nbt && J + p < nt) ? xs[slot * TS + r] : 0.0);
     }
-    // reduce over the 32 rows held by one half-wave
     for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-    if (r == 0) sv[c] = Yb[(int64_t)J * TT + TS * c] - s;
+    double* svb = sv + (J & 1) * TS;
+    if (r == 0) svb[c] = y_cur - s;
     __syncthreads();
-    if (tid < TS) {
-      // x_J = Linv_JJ^T s
-      const double* Li = Linv + (int64_t)J * TT;
-      double xv = 0;
-      for (int rr = tid; rr < TS; ++rr) xv += Li[rr + TS * tid] * sv[rr];
-      xs[(J % (nbt + 1)) * TS + tid] = xv;
-      if (J * TS + tid < n) x_out[J * TS + tid] = xv;
+    // x_J[c] = sum_r Linv[r][c] * sv[r]  (Linv lower: r >= c)
+    double t = (r >= c) ? li_cur * svb[r] : 0.0;
+    for (int off = 16; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+    if (r == 0) {
+      xs[(J % (nbt + 1)) * TS + c] = t;
+      if (J * TS + c < n) x_out[J * TS + c] = t;
     }
     __syncthreads();
+#pragma unroll
+    for (int p = 0; p < MAXB; ++p) cur[p] = nxt[p];
+    li_cur = li_nxt; y_cur = y_nxt;
   }
 }
 

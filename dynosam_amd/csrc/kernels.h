@@ -648,22 +648,65 @@ __device__ __forceinline__ void tile_potrf(double* __restrict__ D, double* __res
   __syncthreads();
 }
 
-// X (TS rows) = A L^-T: one lane per row, row held in registers; L (lower) is read from LDS as
-// broadcasts.  Right-looking: once x[c] is known every later column is updated independently, so
-// the FMAs pipeline (no dependent accumulation chain).
-__device__ __forceinline__ void tile_trsm_row(const double* __restrict__ L, const double* __restrict__ dinv,
-                                              double* __restrict__ Arow_tile, int r) {
-  double x[TS];
+// Blocked X = A L^-T for the (up to) two panel tiles of a workgroup, all 256 lanes busy.
+// lane -> (row = tid & 63 : rows 0..31 of P, 32..63 of Q ; cp = tid >> 6 : column pair inside an
+// 8-column block).  For each 8-column block cb:
+//   T   = A[:,cb] - X[:, <cb] L[cb, <cb]^T           (independent FMAs, reads X from LDS)
+//   X_cb = T (L[cb,cb]^-1)^T                          (8x8 inverse blocks Li8, computed once)
+__device__ __forceinline__ void tile_trsm_blocked(const double* __restrict__ L, const double* __restrict__ dinv,
+                                                  double* __restrict__ Li8 /*4*64*/, double* __restrict__ P,
+                                                  double* __restrict__ Q, bool have_q, int tid) {
+  if (tid < 32) {
+    // column c0 of the inverse of diagonal 8x8 block b:  L_bb x = e_c0
+    const int b = tid >> 3, c0 = tid & 7, o = 8 * b;
+    double x[8];
 #pragma unroll
-  for (int c = 0; c < TS; ++c) x[c] = Arow_tile[r + TS * c];
+    for (int i = 0; i < 8; ++i) {
+      double sacc = (i == c0) ? 1.0 : 0.0;
 #pragma unroll
-  for (int c = 0; c < TS; ++c) {
-    x[c] *= dinv[c];
+      for (int m = 0; m < i; ++m) sacc -= L[(o + i) + TS * (o + m)] * x[m];
+      x[i] = sacc * dinv[o + i];
+    }
 #pragma unroll
-    for (int m = c + 1; m < TS; ++m) x[m] -= x[c] * L[m + TS * c];
+    for (int i = 0; i < 8; ++i) Li8[b * 64 + i * 8 + c0] = x[i];   // Li[i][c0], zero above the diagonal
   }
+  __syncthreads();
+  const int row = tid & 63, cp = tid >> 6, r = row & 31;
+  double* A = (row < 32) ? P : Q;
+  const bool active = (row < 32) || have_q;
 #pragma unroll
-  for (int c = 0; c < TS; ++c) Arow_tile[r + TS * c] = x[c];
+  for (int cb = 0; cb < 4; ++cb) {
+    const int c0 = 8 * cb + 2 * cp, c1 = c0 + 1;
+    double t0 = 0, t1 = 0;
+    if (active) {
+      t0 = A[r + TS * c0];
+      t1 = A[r + TS * c1];
+#pragma unroll
+      for (int m = 0; m < 8 * cb; ++m) {
+        const double xm = A[r + TS * m];
+        t0 -= xm * L[c0 + TS * m];
+        t1 -= xm * L[c1 + TS * m];
+      }
+      A[r + TS * c0] = t0;
+      A[r + TS * c1] = t1;
+    }
+    __syncthreads();
+    double x0 = 0, x1 = 0;
+    if (active) {
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const double tv = A[r + TS * (8 * cb + m)];
+        x0 += tv * Li8[cb * 64 + (2 * cp) * 8 + m];
+        x1 += tv * Li8[cb * 64 + (2 * cp + 1) * 8 + m];
+      }
+    }
+    __syncthreads();
+    if (active) {
+      A[r + TS * c0] = x0;
+      A[r + TS * c1] = x1;
+    }
+    __syncthreads();
+  }
 }
 
 // Sb/Rb: the (updated) matrix and rhs tiles, read-only for column J during step J;
@@ -677,6 +720,7 @@ __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ Sb, doub
   __shared__ __attribute__((aligned(16))) double Q[TT];
   __shared__ __attribute__((aligned(16))) double colbuf[2 * TS];
   __shared__ double dinv[TS];
+  __shared__ double Li8[4 * 64];
   const int tid = threadIdx.x;
   const int p = roles[blockIdx.x].x, q = roles[blockIdx.x].y;
   const bool p_rhs = (p == nbt + 1);
@@ -719,9 +763,7 @@ __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ Sb, doub
     reinterpret_cast<double2*>(Q)[tid + 256] = q1;
   }
   __syncthreads();
-  if (tid < TS) tile_trsm_row(D, dinv, P, tid);
-  else if (tid >= 64 && tid < 64 + TS && need_q) tile_trsm_row(D, dinv, Q, tid - 64);
-  __syncthreads();
+  tile_trsm_blocked(D, dinv, Li8, P, Q, need_q, tid);
   if (dbg_mode == 3) { if (P[tid] == 1.2345e-300) Lb[0] = 0; return; }
   if (q == 0) {
     store_tile(p_rhs ? Yb + (int64_t)J * TT : Lb + (colJ + p) * TT, P, tid);

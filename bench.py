@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-collective", action="store_true", help="use the RCCL all-reduce path even with one rank (plumbing check)")
     args = ap.parse_args()
 
     import numpy as np
@@ -49,7 +50,10 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    collective = world > 1 or args.force_collective
+    if collective:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from dynosam_amd import synth
@@ -78,7 +82,7 @@ def main():
             dist.all_reduce(buf, op=dist.ReduceOp.SUM)
         stream.synchronize()
 
-    ctx = Context(device=local_rank, world_size=world, rank=rank, allreduce=allreduce if world > 1 else None,
+    ctx = Context(device=local_rank, world_size=world, rank=rank, allreduce=allreduce if collective else None,
                   stream=stream.cuda_stream)
     ctx.upload(shard)
 
@@ -91,7 +95,7 @@ def main():
         return ctx.optimize(P)
 
     def sync():
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -104,7 +108,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if collective:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     steps_done = int(rep.iterations)
@@ -142,7 +146,7 @@ def main():
         else:
             out["cpu_baseline"] = None
     ctx.close()
-    if world > 1:
+    if collective:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

@@ -7,7 +7,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = ["dynogfx.hip"]
-DEPS = ["dynogfx.hip", "kernels.h", "dev_factors.h", "dev_se3.h", os.path.join("..", "..", "include", "dynogfx.h")]
+DEPS = ["dynogfx.hip", "kernels.h", "chol_tiles.h", "tile_sym.h", "dev_factors.h", "dev_se3.h", os.path.join("..", "..", "include", "dynogfx.h")]
 OUT = os.path.join(HERE, "libdynogfx.so")
 
 

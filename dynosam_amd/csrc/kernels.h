@@ -517,6 +517,29 @@ __global__ void k_assemble_final(AssembleView A, const double* __restrict__ part
   if (gi >= gj) Sb[band_addr(gi, gj, A.nbt)] = acc;
 }
 
+// pass 2, tile-sparse layout: the block lands at scalar offsets (off[a], off[b]) of the tiled matrix;
+// blocks whose row variable precedes the column variable in the elimination layout are stored transposed.
+// blk_tile[4 blk + ti + 2 tj] = tile id of tile (R0/TS + ti, C0/TS + tj), R0 = max(off), C0 = min(off).
+__global__ void k_assemble_final_tiles(AssembleView A, const double* __restrict__ partial, const double* __restrict__ lambda_p,
+                                       double add_lambda, const int32_t* __restrict__ off, const int32_t* __restrict__ blk_tile,
+                                       double* __restrict__ At) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t blk = t / 36;
+  const int el = (int)(t % 36);
+  if (blk >= A.n_blk) return;
+  const int i = el / 6, j = el % 6;
+  const int a = A.blk_a[blk], b = A.blk_b[blk];
+  if (a == b && j > i) return;
+  double acc = (a == b && i == j) ? add_lambda * (*lambda_p) : 0.0;
+  for (int c = A.blk_ch[blk]; c < A.blk_ch[blk + 1]; ++c) acc += partial[(int64_t)c * 36 + el];
+  const int oa = off[a], ob = off[b];
+  int gi = oa + i, gj = ob + j;
+  if (oa < ob) { const int tmp = gi; gi = gj; gj = tmp; }
+  const int R0 = oa > ob ? oa : ob, C0 = oa > ob ? ob : oa;
+  const int tile = blk_tile[4 * blk + (gi / TS - R0 / TS) + 2 * (gj / TS - C0 / TS)];
+  At[(int64_t)tile * TT + (gi % TS) + TS * (gj % TS)] = acc;
+}
+
 struct RhsView {
   int64_t n_pose;
   const int32_t* pi_ptr;   // [n_pose+1] pose-factor incidence

@@ -28,11 +28,20 @@ constexpr int CT_LD = 33;                 // LDS leading dimension of a staged t
 constexpr int CT_TILE_LDS = CT_LD * CT_TS;
 typedef double ct_d4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ double ct_rsqrt(double x) {
-  double r = __builtin_amdgcn_rsq(x);
-  r = r * fma(-0.5 * x * r, r, 1.5);
-  r = r * fma(-0.5 * x * r, r, 1.5);
+__device__ __forceinline__ double ct_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
   return r;
+}
+// 1/sqrt(x) to full fp64 precision.  The raw v_rsq_f64 seed is good to 2^-24 (measured,
+// scripts/ubench/dp_lat.hip), so ONE third-order step r (1 + e/2 + 3 e^2/8), e = 1 - x r^2, reaches
+// 2^-72: five dependent fp64 ops (~5 cycles each, issue bound) instead of two Newton steps.
+__device__ __forceinline__ double ct_rsqrt(double x) {
+  const double r = __builtin_amdgcn_rsq(x);
+  const double e = fma(-(x * r), r, 1.0);
+  const double q = e * fma(0.375, e, 0.5);
+  return fma(r, q, r);
 }
 
 // global tile (column-major 32x32, 8 KB) -> LDS (ld 33); 256 lanes, 16 B per lane per trip
@@ -45,6 +54,22 @@ __device__ __forceinline__ void ct_g2l(const double* __restrict__ g, double* __r
     const int e = idx * 2, r = e & 31, c = e >> 5;
     l[r + CT_LD * c] = v.x;
     l[r + 1 + CT_LD * c] = v.y;
+  }
+}
+// split form: issue every global load of a task first, land them in LDS afterwards
+struct ct_t2 { double2 a, b; };
+__device__ __forceinline__ ct_t2 ct_gld(const double* __restrict__ g, int tid) {
+  const double2* g2 = reinterpret_cast<const double2*>(g);
+  return {g2[tid], g2[tid + 256]};
+}
+__device__ __forceinline__ void ct_lst(double* __restrict__ l, int tid, const ct_t2& v) {
+  {
+    const int e = tid * 2, r = e & 31, c = e >> 5;
+    l[r + CT_LD * c] = v.a.x; l[r + 1 + CT_LD * c] = v.a.y;
+  }
+  {
+    const int e = (tid + 256) * 2, r = e & 31, c = e >> 5;
+    l[r + CT_LD * c] = v.b.x; l[r + 1 + CT_LD * c] = v.b.y;
   }
 }
 __device__ __forceinline__ void ct_l2g(double* __restrict__ g, const double* __restrict__ l, int tid) {
@@ -99,6 +124,33 @@ __device__ __forceinline__ ct_d4 ct_load_frag(const double* __restrict__ T, int 
 //      update c -= X X^T is NB/4 MFMAs per fragment, and the same X values ARE the output columns.
 // ------------------------------------------------------------------------------------------
 template <int NB>
+struct CtBlk {            // per-lane (redundant) factorisation of one NB x NB diagonal block, LDL^T form
+  double T[NB][NB];       // T[i][k] = C[i][k] / d_k  (i > k), C = running Schur complement
+  double rs[NB];          // 1 / sqrt(d_k)
+};
+// X = p L^-T for one row of the panel (p = NB values at pb[row*NB ..]); returns the NB/4 MFMA operands
+// X[lr + 4 kk] of this lane.
+template <int NB>
+__device__ __forceinline__ void ct_row_solve(const CtBlk<NB>& B, const double* __restrict__ rsel, const double* __restrict__ prow, int lr,
+                                             double* __restrict__ out) {
+  double x[NB];
+#pragma unroll
+  for (int k = 0; k < NB; ++k) {
+    double v = prow[k];
+#pragma unroll
+    for (int m = 0; m < k; ++m) v = fma(-x[m], B.T[k][m], v);
+    x[k] = v;
+  }
+#pragma unroll
+  for (int kk = 0; kk < NB / 4; ++kk) {
+    double v = x[4 * kk];
+#pragma unroll
+    for (int q = 1; q < 4; ++q) v = (lr == q) ? x[4 * kk + q] : v;
+    out[kk] = v * rsel[kk];
+  }
+}
+
+template <int NB>
 __device__ __forceinline__ void ct_tall_potrf(ct_d4 c0, ct_d4 c1, double* __restrict__ pan /*2*64*NB*/, double* __restrict__ Lout,
                                               double* __restrict__ LIout, int tid, int col0, int* __restrict__ fail) {
   const int w = tid >> 6, lane = tid & 63, lr = lane >> 4, lc = lane & 15;
@@ -115,64 +167,60 @@ __device__ __forceinline__ void ct_tall_potrf(ct_d4 c0, ct_d4 c1, double* __rest
       for (int r = 0; r < 4; ++r) pb[(16 * w + lr + 4 * r) * NB + (lc - cin)] = s[r];
     }
     __syncthreads();
-    // diagonal block (lower) -> Cholesky factor Lb and W = Lb^-1, redundantly per lane
-    double Lb[NB][NB], W[NB][NB], rs[NB];
+    // LDL^T form: T = C / d, outputs scaled by rs = 1/sqrt(d) afterwards.  The wave is issue bound here
+    // (one wave per SIMD, ~5 cycles per fp64 op), so the op count per pivot is what matters.
+    CtBlk<NB> B;
+    {
+      double C[NB][NB];
 #pragma unroll
-    for (int a = 0; a < NB; ++a)
+      for (int i = 0; i < NB; ++i)
 #pragma unroll
-      for (int b = 0; b < NB; ++b) { Lb[a][b] = (b <= a) ? pb[(cbase + a) * NB + b] : 0.0; W[a][b] = 0.0; }
+        for (int j = 0; j <= i; ++j) C[i][j] = pb[(cbase + i) * NB + j];
 #pragma unroll
-    for (int k = 0; k < NB; ++k) {
-      double d = Lb[k][k];
+      for (int k = 0; k < NB; ++k) {
+        double d = C[k][k];
+        const bool pos = d > 0.0;
+        if (!pos && ok) { ok = false; bad = col0 + cbase + k; }
+        d = pos ? d : 1.0;
+        B.rs[k] = ct_rsqrt(d);
+        const double inv = B.rs[k] * B.rs[k];
 #pragma unroll
-      for (int m = 0; m < k; ++m) d = fma(-Lb[k][m], Lb[k][m], d);
-      const bool pos = d > 0.0;
-      if (!pos && ok) { ok = false; bad = col0 + cbase + k; }
-      d = pos ? d : 1.0;
-      rs[k] = ct_rsqrt(d);
-      Lb[k][k] = d * rs[k];
+        for (int i = k + 1; i < NB; ++i) B.T[i][k] = C[i][k] * inv;
 #pragma unroll
-      for (int i = k + 1; i < NB; ++i) {
-        double s = Lb[i][k];
+        for (int i = k + 1; i < NB; ++i)
 #pragma unroll
-        for (int m = 0; m < k; ++m) s = fma(-Lb[i][m], Lb[k][m], s);
-        Lb[i][k] = s * rs[k];
+          for (int j = k + 1; j <= i; ++j) C[i][j] = fma(-B.T[i][k], C[j][k], C[i][j]);
       }
     }
-#pragma unroll
-    for (int k = 0; k < NB; ++k) {
-      W[k][k] = rs[k];
-#pragma unroll
-      for (int i = k + 1; i < NB; ++i) {
-        double s = 0.0;
-#pragma unroll
-        for (int m = k; m < i; ++m) s = fma(Lb[i][m], W[m][k], s);
-        W[i][k] = -s * rs[i];
-      }
-    }
-    // operands: k = lr + 4 kk
+    const bool need0 = cbase + NB < 16;    // fragment c0 (columns 0..15) still has unfinished columns
+    double xa[NB / 4], xb0[NB / 4], xb1[NB / 4], rsel[NB / 4];
 #pragma unroll
     for (int kk = 0; kk < NB / 4; ++kk) {
-      double wr[NB];
+      double v = B.rs[4 * kk];
 #pragma unroll
-      for (int m = 0; m < NB; ++m) {
-        double v = W[4 * kk][m];
+      for (int q = 1; q < 4; ++q) v = (lr == q) ? B.rs[4 * kk + q] : v;
+      rsel[kk] = v;
+    }
+    ct_row_solve<NB>(B, rsel, pb + irow * NB, lr, xa);
+    if (w == 0) {
 #pragma unroll
-        for (int q = 1; q < 4; ++q) v = (lr == q) ? W[4 * kk + q][m] : v;
-        wr[m] = v;
-      }
-      double xa = 0.0, xb0 = 0.0, xb1 = 0.0;
+      for (int kk = 0; kk < NB / 4; ++kk) xb0[kk] = xa[kk];
+    } else if (need0) {
+      ct_row_solve<NB>(B, rsel, pb + lc * NB, lr, xb0);
+    }
+    if (w == 1) {
 #pragma unroll
-      for (int m = 0; m < NB; ++m) {
-        xa = fma(pb[irow * NB + m], wr[m], xa);
-        xb0 = fma(pb[lc * NB + m], wr[m], xb0);
-        xb1 = fma(pb[(16 + lc) * NB + m], wr[m], xb1);
-      }
-      if (cbase + NB < 16) c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa, xb0, c0, 0, 0, 0);
-      if (cbase + NB < 32) c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa, xb1, c1, 0, 0, 0);
+      for (int kk = 0; kk < NB / 4; ++kk) xb1[kk] = xa[kk];
+    } else {
+      ct_row_solve<NB>(B, rsel, pb + (16 + lc) * NB, lr, xb1);
+    }
+#pragma unroll
+    for (int kk = 0; kk < NB / 4; ++kk) {
+      if (need0) c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa[kk], xb0[kk], c0, 0, 0, 0);
+      if (cbase + NB < 32) c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa[kk], xb1[kk], c1, 0, 0, 0);
       const int kcol = cbase + 4 * kk + lr;
-      if (w < 2) Lout[irow + CT_LD * kcol] = (irow >= kcol) ? xa : 0.0;
-      else LIout[kcol + CT_LD * (irow - 32)] = xa;     // Linv[kcol][i'] = (Linv^T)[i'][kcol]
+      if (w < 2) Lout[irow + CT_LD * kcol] = (irow >= kcol) ? xa[kk] : 0.0;
+      else LIout[kcol + CT_LD * (irow - 32)] = xa[kk];     // Linv[kcol][i'] = (Linv^T)[i'][kcol]
     }
   }
   if (!ok && tid == 0) atomicMin(fail, bad);
@@ -189,11 +237,16 @@ struct CholLevelArgs {
   double* Y;       // [nt*32] L^-1 g
   double* Wv;      // [nt*32] Linv_K^T y_K
   int* fail;
+  long long* dbg;  // optional phase timestamps of the first finalising workgroup of each launch (s_memtime ticks)
 };
 
-constexpr int CT_NB = 4;
+#ifndef CT_NB_VALUE
+#define CT_NB_VALUE 4
+#endif
+constexpr int CT_NB = CT_NB_VALUE;   // columns per panel step of the diagonal-tile factorisation
+#define CT_STAMP(k) do { if (dbg_on) a.dbg[16 * lvl + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
 
-__global__ __launch_bounds__(256) void k_chol_level(CholLevelArgs a, int task0) {
+__global__ __launch_bounds__(256) void k_chol_level(CholLevelArgs a, int task0, int lvl) {
   __shared__ __attribute__((aligned(16))) double XA[CT_TILE_LDS];
   __shared__ __attribute__((aligned(16))) double XB[CT_TILE_LDS];
   __shared__ __attribute__((aligned(16))) double LI[CT_TILE_LDS];
@@ -204,11 +257,13 @@ __global__ __launch_bounds__(256) void k_chol_level(CholLevelArgs a, int task0) 
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, bi = w >> 1, bj = w & 1;
   const FwdTask t = a.task[task0 + blockIdx.x];
   const ct_d4 zero = {0.0, 0.0, 0.0, 0.0};
+  const bool dbg_on = a.dbg && blockIdx.x == 0 && tid == 0 && (t.kind & FK_FINAL);
+  CT_STAMP(0);
 
   if (t.kind & FK_PANEL) {
-    const FwdSrc s = a.src[t.src0];
-    ct_g2l(a.A + (int64_t)s.ai * CT_TT, XA, tid);
-    ct_g2l(a.Linv + (int64_t)s.k * CT_TT, LI, tid);
+    const ct_t2 va = ct_gld(a.A + (int64_t)t.ai0 * CT_TT, tid), vl = ct_gld(a.Linv + (int64_t)t.k0 * CT_TT, tid);
+    ct_lst(XA, tid, va);
+    ct_lst(LI, tid, vl);
     __syncthreads();
     const ct_d4 p = ct_mma_abt<false>(XA, LI, bi, bj, lane, zero);
     ct_store_frag(Pt, bi, bj, lane, p);
@@ -218,18 +273,32 @@ __global__ __launch_bounds__(256) void k_chol_level(CholLevelArgs a, int task0) 
   }
 
   const bool diag = (t.kind & FK_DIAG) != 0;
-  ct_g2l(a.A + (int64_t)t.tgt * CT_TT, Qt, tid);
   double rv = 0.0;
-  if (diag && tid < CT_TS) rv = a.rhs[t.col * CT_TS + tid];
   ct_d4 acc = zero;
-  for (int q = 0; q < t.nsrc; ++q) {
-    const FwdSrc s = a.src[t.src0 + q];
-    if (q) __syncthreads();            // previous source fully consumed
-    ct_g2l(a.A + (int64_t)s.ai * CT_TT, XA, tid);
-    if (!diag) ct_g2l(a.A + (int64_t)s.aj * CT_TT, XB, tid);
-    ct_g2l(a.Linv + (int64_t)s.k * CT_TT, LI, tid);
-    if (diag && tid < CT_TS) wk[tid] = a.Wv[s.k * CT_TS + tid];
+  for (int q = 0; q < t.nsrc || q == 0; ++q) {
+    // the first source rides in the task record (one dependent load less on the critical path)
+    FwdSrc s{t.ai0, t.aj0, t.k0};
+    if (q) { s = a.src[t.src0 + q]; __syncthreads(); }   // previous source fully consumed
+    ct_t2 vt, va, vb, vl;
+    double wv = 0.0;
+    if (q == 0) {
+      vt = ct_gld(a.A + (int64_t)t.tgt * CT_TT, tid);
+      if (diag && tid < CT_TS) rv = a.rhs[t.col * CT_TS + tid];
+    }
+    if (t.nsrc) {
+      va = ct_gld(a.A + (int64_t)s.ai * CT_TT, tid);
+      if (!diag) vb = ct_gld(a.A + (int64_t)s.aj * CT_TT, tid);
+      vl = ct_gld(a.Linv + (int64_t)s.k * CT_TT, tid);
+      if (diag && tid < CT_TS) wv = a.Wv[s.k * CT_TS + tid];
+    }
+    if (q == 0) ct_lst(Qt, tid, vt);
+    if (t.nsrc == 0) break;
+    ct_lst(XA, tid, va);
+    if (!diag) ct_lst(XB, tid, vb);
+    ct_lst(LI, tid, vl);
+    if (diag && tid < CT_TS) wk[tid] = wv;
     __syncthreads();
+    CT_STAMP(1);
     if (q == 0) acc = ct_load_frag(Qt, bi, bj, lane);
     const ct_d4 p = ct_mma_abt<false>(XA, LI, bi, bj, lane, zero);
     ct_d4 qq = zero;
@@ -255,6 +324,7 @@ __global__ __launch_bounds__(256) void k_chol_level(CholLevelArgs a, int task0) 
   }
   if (t.nsrc == 0) { __syncthreads(); acc = ct_load_frag(Qt, bi, bj, lane); }
   __syncthreads();                     // Pt/Qt no longer read as operands
+  CT_STAMP(2);
 
   if (!(t.kind & FK_FINAL)) {
     ct_store_frag(Pt, bi, bj, lane, acc);
@@ -281,10 +351,13 @@ __global__ __launch_bounds__(256) void k_chol_level(CholLevelArgs a, int task0) 
       c1[r] = (ip == 16 + lc) ? 1.0 : 0.0;
     }
   }
+  CT_STAMP(3);
   // outputs: L -> XA, Linv -> XB; panel buffer -> LI
   ct_tall_potrf<CT_NB>(c0, c1, LI, XA, XB, tid, t.col * CT_TS, a.fail);
+  CT_STAMP(4);
   ct_l2g(a.L + (int64_t)t.tgt * CT_TT, XA, tid);
   ct_l2g(a.Linv + (int64_t)t.col * CT_TT, XB, tid);
+  CT_STAMP(5);
   {
     // y = Linv r ; w = Linv^T y      (Linv[r][c] at XB[r + LD c], zero above the diagonal)
     const int i = tid & 31, kg = tid >> 5;
@@ -313,6 +386,7 @@ __global__ __launch_bounds__(256) void k_chol_level(CholLevelArgs a, int task0) 
       a.Wv[t.col * CT_TS + tid] = ssum;
     }
   }
+  CT_STAMP(6);
 }
 
 struct BackLevelArgs {
@@ -329,9 +403,19 @@ __global__ __launch_bounds__(256) void k_back_level(BackLevelArgs a, int task0) 
   __shared__ double v[CT_TS];
   const int tid = threadIdx.x, c = tid >> 3, rg = tid & 7;
   const BwdTask t = a.task[task0 + blockIdx.x];
+  // everything that does not depend on the sources is requested first
+  const double sprev = a.S[t.j * CT_TS + c];
+  double yv = 0.0;
+  double2 i0 = make_double2(0, 0), i1 = i0;
+  if (t.finalize) {
+    yv = a.Y[t.j * CT_TS + c];
+    const double2* ip = reinterpret_cast<const double2*>(a.Linv + (int64_t)t.j * CT_TT + 4 * rg + CT_TS * c);
+    i0 = ip[0]; i1 = ip[1];
+  }
   double acc = 0.0;
+  BwdSrc s{t.tile0, t.i0};
   for (int q = 0; q < t.nsrc; ++q) {
-    const BwdSrc s = a.src[t.src0 + q];
+    if (q) s = a.src[t.src0 + q];
     const double2* lp = reinterpret_cast<const double2*>(a.L + (int64_t)s.tile * CT_TT + 4 * rg + CT_TS * c);
     const double2* xp = reinterpret_cast<const double2*>(a.X + s.i * CT_TS + 4 * rg);
     const double2 l0 = lp[0], l1 = lp[1], x0 = xp[0], x1 = xp[1];
@@ -340,16 +424,14 @@ __global__ __launch_bounds__(256) void k_back_level(BackLevelArgs a, int task0) 
   acc += __shfl_xor(acc, 1, 64);
   acc += __shfl_xor(acc, 2, 64);
   acc += __shfl_xor(acc, 4, 64);
-  if (rg == 0) {
-    const double sn = a.S[t.j * CT_TS + c] + acc;
-    if (t.finalize) v[c] = a.Y[t.j * CT_TS + c] - sn;
-    else a.S[t.j * CT_TS + c] = sn;
+  const double sn = sprev + acc;
+  if (!t.finalize) {
+    if (rg == 0) a.S[t.j * CT_TS + c] = sn;
+    return;
   }
-  if (!t.finalize) return;
+  if (rg == 0) v[c] = yv - sn;
   __syncthreads();
-  const double2* lp = reinterpret_cast<const double2*>(a.Linv + (int64_t)t.j * CT_TT + 4 * rg + CT_TS * c);
-  const double2 l0 = lp[0], l1 = lp[1];
-  double x = (l0.x * v[4 * rg] + l0.y * v[4 * rg + 1]) + (l1.x * v[4 * rg + 2] + l1.y * v[4 * rg + 3]);
+  double x = (i0.x * v[4 * rg] + i0.y * v[4 * rg + 1]) + (i1.x * v[4 * rg + 2] + i1.y * v[4 * rg + 3]);
   x += __shfl_xor(x, 1, 64);
   x += __shfl_xor(x, 2, 64);
   x += __shfl_xor(x, 4, 64);

@@ -287,12 +287,12 @@ __global__ void k_error(BlockView B, const double* __restrict__ poses, const dou
 
 // linearised error pieces per factor: lin[2f] = 0.5||b||^2, lin[2f+1] = 0.5||A delta - b||^2
 template <int T>
-__global__ void k_lin_error(BlockView B, const double* __restrict__ Jbuf, const double* __restrict__ dpose,
+__global__ void k_lin_error(BlockView B, const double* const* __restrict__ Jpp, const double* __restrict__ dpose,
                             const double* __restrict__ dpoint, double* __restrict__ lin) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B.count) return;
   constexpr int D = f_dim(T);
-  const double* rec = Jbuf + B.rec0 + i * f_rec(T);
+  const double* rec = *Jpp + B.rec0 + i * f_rec(T);
   const int32_t* v = B.vidx + i * f_arity(T);
   double res[D];
   double b2 = 0;
@@ -360,10 +360,11 @@ struct PointView {
 };
 
 // C = L^-T (upper, 6 values: c00 c01 c02 c11 c12 c22), u = L^-1 g
-__global__ void k_point(PointView P, const double* __restrict__ Jbuf, const double* __restrict__ lambda_p,
+__global__ void k_point(PointView P, const double* const* __restrict__ Jpp, const double* __restrict__ lambda_p,
                         double* __restrict__ Cq, double* __restrict__ uq, int* __restrict__ fail_flag) {
   const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= P.n_point) return;
+  const double* __restrict__ Jbuf = *Jpp;
   const double lambda = *lambda_p;
   double h00 = lambda, h01 = 0, h02 = 0, h11 = lambda, h12 = 0, h22 = lambda, g0 = 0, g1 = 0, g2 = 0;
   for (int k = P.pf_ptr[q]; k < P.pf_ptr[q + 1]; ++k) {
@@ -410,9 +411,10 @@ struct EdgeView {
   const int64_t* e_jp;     // offset of Jp (3x3)
 };
 
-__global__ void k_edge_z(EdgeView E, const double* __restrict__ Jbuf, const double* __restrict__ Cq, double* __restrict__ Z) {
+__global__ void k_edge_z(EdgeView E, const double* const* __restrict__ Jpp, const double* __restrict__ Cq, double* __restrict__ Z) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E.n_edge) return;
+  const double* __restrict__ Jbuf = *Jpp;
   const double* Jc = Jbuf + E.e_jc[e];
   const double* Jp = Jbuf + E.e_jp[e];
   const double* C = Cq + 6 * (int64_t)E.e_point[e];
@@ -460,8 +462,9 @@ struct AssembleView {
 // chunk's indices (one contribution per lane, coalesced), then lanes 0..35 = (i,j) walk the chunk
 // with the indices broadcast by readlane, so the Z / J loads of successive contributions are
 // independent and pipeline.  Fixed order => deterministic.
-__global__ __launch_bounds__(256) void k_assemble_chunks(AssembleView A, const double* __restrict__ Jbuf,
+__global__ __launch_bounds__(256) void k_assemble_chunks(AssembleView A, const double* const* __restrict__ Jpp,
                                                          const double* __restrict__ Z, double* __restrict__ partial) {
+  const double* __restrict__ Jbuf = *Jpp;
   const int64_t ch = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (ch >= A.n_chunk) return;
@@ -552,8 +555,9 @@ struct RhsView {
 };
 
 // one wavefront per pose; fixed lane partition + butterfly reduction => deterministic
-__global__ __launch_bounds__(256) void k_rhs(RhsView R, const double* __restrict__ Jbuf, const double* __restrict__ Z,
+__global__ __launch_bounds__(256) void k_rhs(RhsView R, const double* const* __restrict__ Jpp, const double* __restrict__ Z,
                                              const double* __restrict__ uq, double* __restrict__ gc) {
+  const double* __restrict__ Jbuf = *Jpp;
   const int64_t a = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (a >= R.n_pose) return;

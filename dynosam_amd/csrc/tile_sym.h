@@ -37,6 +37,7 @@ struct FwdTask {
   int32_t nsrc;
   int32_t kind;   // bit0: diagonal target (carries the rhs segment), bit1: finalize (potrf + Linv + y,w), bit2: panel store
   int32_t col;    // tile column of a diagonal target (rhs segment index); -1 otherwise
+  int32_t ai0, aj0, k0;   // copy of the first source (saves a dependent load on the device)
 };
 struct FwdSrc {
   int32_t ai;     // tile id of A(I ,K)
@@ -47,6 +48,7 @@ struct BwdTask {
   int32_t j;        // target tile column
   int32_t src0, nsrc;
   int32_t finalize; // x_j = Linv_j^T (y_j - s_j)
+  int32_t tile0, i0;   // copy of the first source
 };
 struct BwdSrc {
   int32_t tile;   // tile id of L(I,J)
@@ -122,7 +124,7 @@ struct TileSym {
     std::vector<std::vector<int32_t>> by_level(n_levels);
     for (int J = 0; J < nt; ++J) by_level[level[J]].push_back(J);
     // launch 0: leaves
-    for (int J : by_level[0]) { ftask.push_back({diag(J), 0, 0, FK_DIAG | FK_FINAL, J}); flops_factor += 3 * T3; }
+    for (int J : by_level[0]) { ftask.push_back({diag(J), 0, 0, FK_DIAG | FK_FINAL, J, 0, 0, 0}); flops_factor += 3 * T3; }
     flaunch.push_back((int32_t)ftask.size());
     for (int l = 0; l < n_levels; ++l) {
       std::map<int32_t, std::vector<FwdSrc>> groups;   // target tile id -> sources (ordered by K: deterministic)
@@ -131,7 +133,7 @@ struct TileSym {
       for (int K : by_level[l]) {
         const int32_t b = col_ptr[K] + 1, e = col_ptr[K + 1];
         for (int32_t x = b; x < e; ++x) {
-          panel.push_back({x, 0, 1, FK_PANEL, -1});
+          panel.push_back({x, 0, 1, FK_PANEL, -1, x, x, K});
           panel_src.push_back({x, x, K});
           for (int32_t y = b; y <= x; ++y) {
             const int32_t t = find(row_idx[x], row_idx[y]);
@@ -152,7 +154,7 @@ struct TileSym {
       for (auto& o : order) {
         auto& src = groups[o.second];
         const int I = row_idx[src.front().ai];
-        FwdTask t{o.second, (int32_t)fsrc.size(), (int32_t)src.size(), 0, -1};
+        FwdTask t{o.second, (int32_t)fsrc.size(), (int32_t)src.size(), 0, -1, src.front().ai, src.front().aj, src.front().k};
         if (o.first <= 1) { t.kind |= FK_DIAG; t.col = I; }
         if (o.first == 0) { t.kind |= FK_FINAL; flops_factor += 3 * T3; }
         flops_factor += (double)src.size() * ((o.first <= 1) ? 4 * T3 : 6 * T3);
@@ -186,7 +188,8 @@ struct TileSym {
         for (auto& g : bucket[q]) {
           const bool fin = level[g.first] == q;
           if (fin != (pass == 0)) continue;
-          btask.push_back({g.first, (int32_t)bsrc.size(), (int32_t)g.second.size(), fin ? 1 : 0});
+          btask.push_back({g.first, (int32_t)bsrc.size(), (int32_t)g.second.size(), fin ? 1 : 0,
+                           g.second.empty() ? 0 : g.second.front().tile, g.second.empty() ? 0 : g.second.front().i});
           bsrc.insert(bsrc.end(), g.second.begin(), g.second.end());
         }
       blaunch.push_back((int32_t)btask.size());

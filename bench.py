@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-frontend", action="store_true", help="skip the frontend (dense flow + feature propagation) leg")
     ap.add_argument("--force-collective", action="store_true", help="use the RCCL all-reduce path even with one rank (plumbing check)")
     args = ap.parse_args()
 
@@ -145,12 +146,63 @@ def main():
             out["cpu_baseline"] = cpu_baseline(g, base_factors)
         else:
             out["cpu_baseline"] = None
+        if world == 1 and not args.no_frontend:
+            out["frontend"] = frontend_bench(local_rank, cpu=not args.no_cpu_baseline)
     ctx.close()
     if collective:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
+
+
+def frontend_bench(device, cpu=True, frames=50):
+    """BASELINE.json's second metric: frontend frames/sec on 640x480 RGB-D (config 4).  One "frame" = dense flow
+    k -> k+1 (pyramid, descriptors, MFMA correlation volume + arg-max, refinement) + propagation of 1000
+    dynamic features, images already resident in HBM (upload outside the timed region)."""
+    import numpy as np
+    from dynosam_amd import synth_images as SI
+    from dynosam_amd.flow import FlowTracker
+    sc = SI.make_pair(640, 480, objects=3, seed=4)
+    t = FlowTracker(640, 480, device=device)
+    t.upload(sc["rgb0"], sc["mask0"], sc["rgb1"], sc["mask1"])
+    rng = np.random.default_rng(7)
+    ys, xs = np.nonzero(sc["mask0"] > 0)
+    pick = rng.choice(len(xs), 1000, replace=False)
+    kp = np.stack([xs[pick] + 0.5, ys[pick] + 0.5], -1)
+    prev = sc["mask0"][ys[pick], xs[pick]]
+    zeros = np.zeros(1000, np.int64)
+    flow, _ = t.dense_flow()
+    e = np.linalg.norm(flow - sc["flow_gt"], axis=-1)[sc["valid"]]
+    for _ in range(3):
+        t.dense_flow(download=False)
+    stages = dict(ms_gray_pyramid=0.0, ms_descriptors=0.0, ms_correlation=0.0, ms_refine=0.0, ms_track=0.0)
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        t.dense_flow(download=False)
+        r = t.track_dynamic(kp, prev, zeros, zeros)
+        tm = t.timing()
+        for k in stages:
+            stages[k] += tm[k] / frames
+    dt = (time.perf_counter() - t0) / frames
+    corr_tflops = tm["corr_flops"] / (stages["ms_correlation"] * 1e-3) / 1e12
+    out = {"metric": "frontend frames/sec 640x480 RGB-D", "value": 1.0 / dt, "unit": "frame pairs/s", "ms_per_frame": 1e3 * dt,
+           "stages_ms": {k: round(v, 4) for k, v in stages.items()}, "kept_features": int((r["code"] == 0).sum()),
+           "epe_median_px": float(np.median(e)), "epe_below_1px": float((e < 1.0).mean()),
+           "roofline": {"bound": "mfma", "kernel": "k_corr_argmax", "achieved": corr_tflops, "peak": 2500.0, "unit": "TFLOP/s",
+                        "frac": corr_tflops / 2500.0, "traffic": None,
+                        "note": "bf16 32x32x16 MFMA flops issued (windowed all-pairs volume at 1/8 resolution) / HIP-event time"},
+           "data": "synthetic textured scene, exact flow (dynosam_amd/synth_images.py)"}
+    if cpu:
+        from oracle import flow_oracle as FO
+        c0 = time.perf_counter()
+        FO.dense_flow(sc["rgb0"], sc["rgb1"])
+        cdt = time.perf_counter() - c0
+        out["cpu_baseline"] = {"value": 1.0 / cdt, "unit": "frame pairs/s", "cores": 1, "kind": "port",
+                               "sample": f"1 frame pair, {cdt:.2f} s; numpy restatement of the same algorithm (the reference's own "
+                                         "flow producer is off-line RAFT, not in the repository)"}
+    t.close()
+    return out
 
 
 def cpu_baseline(g, base_factors):

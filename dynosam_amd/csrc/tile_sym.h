@@ -69,6 +69,8 @@ struct TileSym {
   std::vector<BwdSrc> bsrc;
   std::vector<int32_t> blaunch;   // [n_blaunch+1]; launch q finalises level (n_levels-1-q)
   double flops_factor = 0;        // fp64 flops of one numeric factorisation incl. the redundant panel re-derivations
+  int n_elim = -1;                // >= 0: PARTIAL factorisation — only tile columns < n_elim are eliminated; the trailing
+                                  // tiles are left holding the Schur complement (marginalisation, SlidingWindowOptimization.cc:157-188)
 
   int32_t find(int I, int J) const {
     const int32_t* b = row_idx.data() + col_ptr[J];
@@ -79,8 +81,9 @@ struct TileSym {
   int32_t diag(int J) const { return col_ptr[J]; }
 
   // lower: list of (I,J), I >= J, tiles holding a structural non-zero of S (duplicates allowed)
-  void analyse(int nt_, std::vector<std::pair<int32_t, int32_t>> lower, bool schedule = true) {
+  void analyse(int nt_, std::vector<std::pair<int32_t, int32_t>> lower, bool schedule = true, int n_elim_ = -1) {
     nt = nt_;
+    n_elim = n_elim_;
     std::vector<std::vector<int32_t>> rows(nt);
     std::sort(lower.begin(), lower.end());
     lower.erase(std::unique(lower.begin(), lower.end()), lower.end());
@@ -124,13 +127,14 @@ struct TileSym {
     std::vector<std::vector<int32_t>> by_level(n_levels);
     for (int J = 0; J < nt; ++J) by_level[level[J]].push_back(J);
     // launch 0: leaves
-    for (int J : by_level[0]) { ftask.push_back({diag(J), 0, 0, FK_DIAG | FK_FINAL, J, 0, 0, 0}); flops_factor += 3 * T3; }
+    for (int J : by_level[0]) { if (n_elim >= 0 && J >= n_elim) continue; ftask.push_back({diag(J), 0, 0, FK_DIAG | FK_FINAL, J, 0, 0, 0}); flops_factor += 3 * T3; }
     flaunch.push_back((int32_t)ftask.size());
     for (int l = 0; l < n_levels; ++l) {
       std::map<int32_t, std::vector<FwdSrc>> groups;   // target tile id -> sources (ordered by K: deterministic)
       std::vector<FwdTask> panel;
       std::vector<FwdSrc> panel_src;
       for (int K : by_level[l]) {
+        if (n_elim >= 0 && K >= n_elim) continue;
         const int32_t b = col_ptr[K] + 1, e = col_ptr[K + 1];
         for (int32_t x = b; x < e; ++x) {
           panel.push_back({x, 0, 1, FK_PANEL, -1, x, x, K});
@@ -147,7 +151,7 @@ struct TileSym {
         const FwdSrc& s0 = g.second.front();
         const int I = row_idx[s0.ai], Ip = row_idx[s0.aj];
         int pr = 2;
-        if (I == Ip) pr = (level[I] == l + 1) ? 0 : 1;
+        if (I == Ip) pr = (level[I] == l + 1 && (n_elim < 0 || I < n_elim)) ? 0 : 1;
         order.push_back({pr, g.first});
       }
       std::stable_sort(order.begin(), order.end(), [](auto& a, auto& b) { return a.first < b.first; });

@@ -383,5 +383,8 @@ def make_hybrid_graph(cfg: ScenarioConfig) -> FlatGraph:
         n = len(var)
         out_blocks.append(FactorBlock(t, slot_of[o:o + n], var, meas, noise, hk, cst))
         o += n
-    meta = dict(cfg=cfg, gt_state=gt_state, n_static=Ns, n_dynamic=Nd, frames=K, objects=J)
+    # birth frame of every variable (the frame whose update inserts it, Formulation-impl.hpp:552-897) and frame of every factor
+    var_frame_all = np.concatenate([H_frame, np.arange(K), s_birth, d_birth]).astype(np.int64)
+    meta = dict(cfg=cfg, gt_state=gt_state, n_static=Ns, n_dynamic=Nd, frames=K, objects=J, var_frame=var_frame_all[order],
+                factor_frame=[np.asarray(b[6], dtype=np.int64) for b in blocks])
     return FlatGraph(var_keys, var_type, var_state, out_blocks, meta)

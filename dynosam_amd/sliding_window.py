@@ -46,13 +46,21 @@ def flatten(values: Dict[int, tuple], blocks: List[KeyedBlock], prior: Optional[
     vt = np.array([values[int(k)][0] for k in keys], dtype=np.uint8)
     st = np.array([values[int(k)][1] for k in keys], dtype=np.float64).reshape(len(keys), 12)
     out = []
+    by_type: Dict[int, List[KeyedBlock]] = {}
     for b in blocks:
-        if not len(b.slot):
-            continue
-        idx = np.searchsorted(keys, b.keys)
-        if not np.array_equal(keys[idx], b.keys):
+        if len(b.slot):
+            by_type.setdefault(b.type, []).append(b)
+    for t, bs in by_type.items():   # ONE struct-of-arrays block per factor class (each block costs a kernel launch per pass)
+        ks = np.concatenate([b.keys for b in bs])
+        idx = np.searchsorted(keys, ks)
+        if (idx >= len(keys)).any() or not np.array_equal(keys[np.minimum(idx, len(keys) - 1)], ks):
             raise KeyError("gtsam::ValuesKeyDoesNotExist")
-        out.append(FactorBlock(b.type, b.slot, idx, b.meas, b.noise, b.huber_k, b.consts))
+        hk = None
+        if any(b.huber_k is not None for b in bs):
+            hk = np.concatenate([b.huber_k if b.huber_k is not None else np.zeros(len(b.slot)) for b in bs])
+        cs = None if bs[0].consts is None else np.concatenate([b.consts for b in bs])
+        out.append(FactorBlock(t, np.concatenate([b.slot for b in bs]), idx, np.concatenate([b.meas for b in bs]),
+                               np.concatenate([b.noise for b in bs]), hk, cs))
     return FlatGraph(keys, vt, st, out, {}, prior)
 
 

@@ -52,8 +52,12 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     collective = world > 1 or args.force_collective
+    # RCCL writes banners / warnings to the C-level stdout: park fd 1 on stderr for the run and keep the real stdout
+    # for the ONE JSON line rank 0 prints at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     if collective:
-        os.environ["NCCL_DEBUG"] = "WARN"   # keep RCCL's version banner off stdout: rank 0 prints exactly one JSON line
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -154,8 +158,9 @@ def main():
     if collective:
         dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
 
 def frontend_bench(device, cpu=True, frames=50):

@@ -69,6 +69,8 @@ struct TileSym {
   std::vector<BwdSrc> bsrc;
   std::vector<int32_t> blaunch;   // [n_blaunch+1]; launch q finalises level (n_levels-1-q)
   double flops_factor = 0;        // fp64 flops of one numeric factorisation incl. the redundant panel re-derivations
+  bool two_phase = false;         // with n_elim >= 0: ALSO schedule the remaining columns as a second phase
+  std::vector<int32_t> phase_end; // index into flaunch where each phase's launches end
   int n_elim = -1;                // >= 0: PARTIAL factorisation — only tile columns < n_elim are eliminated; the trailing
                                   // tiles are left holding the Schur complement (marginalisation, SlidingWindowOptimization.cc:157-188)
 
@@ -81,9 +83,10 @@ struct TileSym {
   int32_t diag(int J) const { return col_ptr[J]; }
 
   // lower: list of (I,J), I >= J, tiles holding a structural non-zero of S (duplicates allowed)
-  void analyse(int nt_, std::vector<std::pair<int32_t, int32_t>> lower, bool schedule = true, int n_elim_ = -1) {
+  void analyse(int nt_, std::vector<std::pair<int32_t, int32_t>> lower, bool schedule = true, int n_elim_ = -1, bool two_phase_ = false) {
     nt = nt_;
     n_elim = n_elim_;
+    two_phase = two_phase_;
     std::vector<std::vector<int32_t>> rows(nt);
     std::sort(lower.begin(), lower.end());
     lower.erase(std::unique(lower.begin(), lower.end()), lower.end());
@@ -120,21 +123,47 @@ struct TileSym {
   }
 
  private:
+  // Forward schedule.  The tile columns are eliminated in one or two PHASES (column ranges): one phase
+  // [0, nt) for a plain factorisation, [0, n_elim) alone for a partial one (marginalisation), and
+  // [0, n_elim) + [n_elim, nt) when something happens in between (multi-GPU: the separator tiles are summed over
+  // ranks after every rank has eliminated its own interior).  Inside a phase the launches follow the levels of
+  // the elimination tree restricted to the phase's columns.
   void build_forward() {
-    ftask.clear(); fsrc.clear(); flaunch.assign(1, 0);
+    ftask.clear(); fsrc.clear(); flaunch.assign(1, 0); phase_end.clear();
     flops_factor = 0;
+    std::vector<std::pair<int, int>> phases;
+    if (n_elim < 0) phases.push_back({0, nt});
+    else {
+      phases.push_back({0, std::min(n_elim, nt)});
+      if (two_phase) phases.push_back({std::min(n_elim, nt), nt});
+    }
+    for (auto& ph : phases) {
+      build_phase(ph.first, ph.second);
+      phase_end.push_back((int32_t)flaunch.size() - 1);
+    }
+  }
+
+  void build_phase(int lo, int hi) {
     const double T3 = 32.0 * 32.0 * 32.0;
-    std::vector<std::vector<int32_t>> by_level(n_levels);
-    for (int J = 0; J < nt; ++J) by_level[level[J]].push_back(J);
-    // launch 0: leaves
-    for (int J : by_level[0]) { if (n_elim >= 0 && J >= n_elim) continue; ftask.push_back({diag(J), 0, 0, FK_DIAG | FK_FINAL, J, 0, 0, 0}); flops_factor += 3 * T3; }
+    std::vector<int32_t> lv(nt, -1);
+    int maxl = -1;
+    for (int J = lo; J < hi; ++J) lv[J] = 0;
+    for (int J = lo; J < hi; ++J) {
+      maxl = std::max(maxl, (int)lv[J]);
+      const int p = parent[J];
+      if (p >= lo && p < hi) lv[p] = std::max(lv[p], lv[J] + 1);
+    }
+    std::vector<std::vector<int32_t>> by_level(maxl + 1);
+    for (int J = lo; J < hi; ++J) by_level[lv[J]].push_back(J);
+    // pre-launch: columns of the phase that receive no update inside it
+    if (maxl >= 0)
+      for (int J : by_level[0]) { ftask.push_back({diag(J), 0, 0, FK_DIAG | FK_FINAL, J, 0, 0, 0}); flops_factor += 3 * T3; }
     flaunch.push_back((int32_t)ftask.size());
-    for (int l = 0; l < n_levels; ++l) {
+    for (int l = 0; l <= maxl; ++l) {
       std::map<int32_t, std::vector<FwdSrc>> groups;   // target tile id -> sources (ordered by K: deterministic)
       std::vector<FwdTask> panel;
       std::vector<FwdSrc> panel_src;
       for (int K : by_level[l]) {
-        if (n_elim >= 0 && K >= n_elim) continue;
         const int32_t b = col_ptr[K] + 1, e = col_ptr[K + 1];
         for (int32_t x = b; x < e; ++x) {
           panel.push_back({x, 0, 1, FK_PANEL, -1, x, x, K});
@@ -151,7 +180,7 @@ struct TileSym {
         const FwdSrc& s0 = g.second.front();
         const int I = row_idx[s0.ai], Ip = row_idx[s0.aj];
         int pr = 2;
-        if (I == Ip) pr = (level[I] == l + 1 && (n_elim < 0 || I < n_elim)) ? 0 : 1;
+        if (I == Ip) pr = (I >= lo && I < hi && lv[I] == l + 1) ? 0 : 1;
         order.push_back({pr, g.first});
       }
       std::stable_sort(order.begin(), order.end(), [](auto& a, auto& b) { return a.first < b.first; });

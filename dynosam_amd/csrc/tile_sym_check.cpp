@@ -81,7 +81,8 @@ int main(int argc, char** argv) {
     g[i] = !is_pad[i] ? U(rng) : 0.0;
   }
   TileSym sym;
-  sym.analyse(nt, lower);
+  const int nel = getenv("TS_NELIM") ? atoi(getenv("TS_NELIM")) : -1;   // two-phase schedule: must still solve the whole system
+  sym.analyse(nt, lower, true, nel < 0 ? -1 : std::min(nel, nt), nel >= 0);
   // tile buffers
   std::vector<double> A((size_t)sym.n_tiles * TT, 0.0), L((size_t)sym.n_tiles * TT, 0.0), Li((size_t)nt * TT), r(g), y(npad), w(npad), s(npad, 0.0), x(npad);
   for (int J = 0; J < nt; ++J)
@@ -160,7 +161,7 @@ int main(int argc, char** argv) {
     rmax = std::max(rmax, std::fabs(acc - g[i]));
     gmax = std::max(gmax, std::fabs(g[i]));
   }
-  printf("nt=%d tiles=%lld levels=%d fwd_launches=%zu fwd_tasks=%zu bwd_tasks=%zu residual=%.3e %s\n", nt, (long long)sym.n_tiles, sym.n_levels,
+  printf("phases=%zu nt=%d tiles=%lld levels=%d fwd_launches=%zu fwd_tasks=%zu bwd_tasks=%zu residual=%.3e %s\n", sym.phase_end.size(), nt, (long long)sym.n_tiles, sym.n_levels,
          sym.flaunch.size() - 1, sym.ftask.size(), sym.btask.size(), rmax / gmax, (rmax / gmax < 1e-10) ? "OK" : "FAIL");
   return (rmax / gmax < 1e-10) ? 0 : 1;
 }

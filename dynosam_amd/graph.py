@@ -228,41 +228,35 @@ class FlatGraph:
             d.prior = C.pointer(pr)
         return d, keep
 
-    # ---- sharding for the multi-GPU path --------------------------------
+    # ---- sharding for the multi-GPU path ----------------------
     def shard(self, rank: int, world_size: int) -> "FlatGraph":
-        """Factors of rank `rank`: every point (and therefore all factors touching it) is owned
-        by one rank — by contiguous ranges of the point's first-observation frame window — and
-        pose-only factors go to the rank owning their latest pose. Variables are replicated."""
+        """Factors of rank `rank`.  Ranks own contiguous, equally long frame windows; a factor belongs to the rank owning
+        its EARLIEST frame — for a factor on a point that is the point's first observation, so every point (and all
+        factors touching it) lives on one rank, and no factor reaches further back than its owner's window: the library
+        relies on exactly this to eliminate each window's interior locally.  Variables are replicated."""
         if world_size == 1:
             return self
-        owner = self.meta.get("factor_owner_frame")
         nvars = self.n_vars
-        # frame index of a pose-like variable = low 48 key bits
-        frame_of_var = (self.var_keys & np.uint64((1 << 48) - 1)).astype(np.int64)
+        frame_of_var = (self.var_keys & np.uint64((1 << 48) - 1)).astype(np.int64)   # frame index = low 48 key bits
         is_pose = self.var_type == VAR_POSE3
-        max_frame = int(frame_of_var[is_pose].max()) if is_pose.any() else 0
-        # first-observation frame per point
-        first = np.full(nvars, np.iinfo(np.int64).max, dtype=np.int64)
+        big = np.iinfo(np.int64).max
+        fmin, fmax = int(frame_of_var[is_pose].min()), int(frame_of_var[is_pose].max())
+        span = fmax - fmin + 1
+        first = np.full(nvars, big, dtype=np.int64)       # first-observation frame per point
         for b in self.blocks:
             ar = F_LAYOUT[b.type][0]
             vt = self.var_type[b.var_idx]
-            pose_frames = np.where(vt == VAR_POSE3, frame_of_var[b.var_idx], np.iinfo(np.int64).max).min(axis=1)
+            pose_frames = np.where(vt == VAR_POSE3, frame_of_var[b.var_idx], big).min(axis=1)
             for a in range(ar):
                 sel = vt[:, a] == VAR_POINT3
                 np.minimum.at(first, b.var_idx[sel, a], pose_frames[sel])
-        del owner
-        # owner frame of every factor: its point's first-observation frame, else its latest pose frame
-        fo = []
+        out = []
         for b in self.blocks:
             vt = self.var_type[b.var_idx]
             has_pt = (vt == VAR_POINT3).any(axis=1)
-            pt_first = np.where(vt == VAR_POINT3, first[b.var_idx], np.iinfo(np.int64).max).min(axis=1)
-            pose_last = np.where(vt == VAR_POSE3, frame_of_var[b.var_idx], -1).max(axis=1)
-            fo.append(np.where(has_pt, pt_first, pose_last))
-        # contiguous keyframe windows holding ~equal factor counts (a frame never straddles two ranks)
-        hist = np.bincount(np.concatenate(fo), minlength=max_frame + 1).astype(np.float64)
-        before = np.concatenate([[0.0], np.cumsum(hist)[:-1]])
-        rank_of_frame = np.minimum((before * world_size / max(1.0, hist.sum())).astype(np.int64), world_size - 1)
-        out = [b.subset(rank_of_frame[f] == rank) for b, f in zip(self.blocks, fo)]
-        g = FlatGraph(self.var_keys, self.var_type, self.var_state, out, dict(self.meta))
-        return g
+            pt_first = np.where(vt == VAR_POINT3, first[b.var_idx], big).min(axis=1)
+            pose_first = np.where(vt == VAR_POSE3, frame_of_var[b.var_idx], big).min(axis=1)
+            owner_frame = np.where(has_pt, pt_first, pose_first)
+            owner = np.minimum(world_size - 1, (owner_frame - fmin) * world_size // span)   # == the library's rank_of(frame)
+            out.append(b.subset(owner == rank))
+        return FlatGraph(self.var_keys, self.var_type, self.var_state, out, dict(self.meta))

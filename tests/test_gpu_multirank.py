@@ -1,0 +1,143 @@
+"""The sharded (multi-GPU) path on ONE GPU: N contexts in one process, one thread per "rank", the all-reduce callback
+implemented with a barrier + torch sums over the wrapped device buffers.  Exercises exactly the code the RCCL path
+runs (factor sharding by earliest frame, local elimination of each window's interior, one SUM of the separator tiles
+per solve, replicated separator solve, SUM of the per-rank pose updates) and compares with the single-context solve of
+the whole graph.  Tolerances: damped solve 1e-6 relative (cond ~1e12), LM: identical accept/reject trace, final cost
+1e-6 relative."""
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from dynosam_amd import synth  # noqa: E402
+
+
+class FakeWorld:
+    """SUM all-reduce over the ranks of one process (device buffers on the same GPU)."""
+
+    def __init__(self, n):
+        import torch
+        self.n, self.torch = n, torch
+        torch.cuda.init()
+        torch.zeros(1, device="cuda")   # initialise torch's HIP context in the main thread
+        self.bar = threading.Barrier(n)
+        self.slots = [None] * n
+        self.calls = [0] * n
+
+    def allreduce(self, rank):
+        torch = self.torch
+
+        def fn(ptr, count):
+            self.calls[rank] += 1
+            st = torch._C._construct_storage_from_data_pointer(ptr, torch.device("cuda", 0), count * 8)
+            buf = torch.empty(0, dtype=torch.float64, device="cuda").set_(st, 0, (count,))
+            self.slots[rank] = buf.clone()
+            torch.cuda.synchronize()
+            self.bar.wait()
+            total = self.slots[0].clone()
+            for r in range(1, self.n):
+                total += self.slots[r]          # fixed order: every rank gets bitwise the same sum
+            buf.copy_(total)
+            torch.cuda.synchronize()
+            self.bar.wait()
+        return fn
+
+
+def run_ranks(g, world, work):
+    from dynosam_amd.optimizer import Context
+    fw = FakeWorld(world)
+    out, err = [None] * world, [None] * world
+
+    def body(r):
+        try:
+            c = Context(device=0, world_size=world, rank=r, allreduce=fw.allreduce(r))
+            c.set_graphs(False)   # stream capture is process-wide state: ranks are threads here, processes in production
+            c.upload(g.shard(r, world))
+            out[r] = work(c)
+            c.close()
+        except BaseException as e:   # noqa: BLE001
+            err[r] = e
+            fw.bar.abort()
+
+    th = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    for e in err:
+        if e is not None:
+            raise e
+    assert len(set(fw.calls)) == 1, fw.calls     # every rank made the same number of collective calls
+    return out
+
+
+def graph(frames=120):
+    return synth.make_hybrid_graph(synth.config(1, frames=frames, objects=2, static_points=6 * frames, dynamic_points_per_object=frames, seed=9))
+
+
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_sharded_damped_solve_matches_single_context(world):
+    from dynosam_amd.optimizer import Context
+    g = graph()
+    c = Context(); c.upload(g)
+    d_ref, dec_ref = c.solve_damped(1e-4)
+    res = run_ranks(g, world, lambda ctx: ctx.solve_damped(1e-4))
+    for d, dec in res:
+        assert np.abs(d - d_ref).max() <= 1e-6 * max(1.0, np.abs(d_ref).max())
+        assert abs(dec - dec_ref) <= 1e-6 * abs(dec_ref)
+    for d, _ in res[1:]:
+        assert np.array_equal(d, res[0][0])          # replicated state stays bitwise identical across ranks
+
+
+def test_sharded_lm_follows_the_same_trace():
+    from dynosam_amd.optimizer import Context
+    g = graph()
+    c = Context(); c.upload(g)
+    r0 = c.optimize()
+    v0 = c.values()
+
+    def work(ctx):
+        r = ctx.optimize()
+        return r, ctx.values()
+
+    res = run_ranks(g, 2, work)
+    for r, v in res:
+        assert r.iterations == r0.iterations and r.inner_iterations == r0.inner_iterations
+        assert [r.trace_accepted[i] for i in range(r.trace_len)] == [r0.trace_accepted[i] for i in range(r0.trace_len)]
+        assert abs(r.error_after - r0.error_after) <= 1e-6 * r0.error_after
+        assert np.abs(v - v0).max() <= 1e-5
+    assert np.array_equal(res[0][1], res[1][1])
+
+
+def test_short_windows_fall_back_to_the_replicated_solve():
+    """windows shorter than two separator widths cannot be dissected: every rank factors the whole reduced system"""
+    from dynosam_amd.optimizer import Context
+    g = synth.make_hybrid_graph(synth.config(1, frames=24, static_points=120, dynamic_points_per_object=24, seed=3))
+    c = Context(); c.upload(g)
+    d_ref, _ = c.solve_damped(1e-4)
+    res = run_ranks(g, 2, lambda ctx: ctx.solve_damped(1e-4))
+    for d, _ in res:
+        assert np.abs(d - d_ref).max() <= 1e-6 * max(1.0, np.abs(d_ref).max())
+
+
+def test_one_rank_collective_path_with_graph_replay():
+    """world_size 1 through the sharded code path (what `bench.py --force-collective` runs): segments replayed from
+    hipGraphs with the collectives between them."""
+    from dynosam_amd.optimizer import Context
+    g = graph(48)
+    c = Context(); c.upload(g)
+    r0 = c.optimize()
+    calls = [0]
+
+    def ident(ptr, count):
+        calls[0] += 1
+
+    c1 = Context(device=0, world_size=1, rank=0, allreduce=ident)
+    c1.upload(g)
+    r1 = c1.optimize()
+    assert calls[0] > 0
+    assert r1.iterations == r0.iterations and r1.inner_iterations == r0.inner_iterations
+    assert abs(r1.error_after - r0.error_after) <= 1e-6 * r0.error_after
+    assert np.abs(c1.values() - c.values()).max() <= 1e-5

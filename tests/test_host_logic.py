@@ -71,7 +71,7 @@ def test_desc_roundtrip():
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_shard_partition(world):
     """every factor on exactly one rank; all factors of a point on the same rank."""
-    g = synth.make_hybrid_graph(synth.config(1, frames=40))
+    g = synth.make_hybrid_graph(synth.config(1, frames=96))
     shards = [g.shard(r, world) for r in range(world)]
     assert sum(s.n_factors for s in shards) == g.n_factors
     slots = np.concatenate([b.slot for s in shards for b in s.blocks])
@@ -83,7 +83,14 @@ def test_shard_partition(world):
             for v in np.unique(b.var_idx[vt == G.VAR_POINT3]):
                 assert owner.setdefault(int(v), r) == r
     counts = np.array([s.n_factors for s in shards])
-    assert counts.min() > 0.3 * counts.mean()          # roughly balanced windows
+    assert counts.min() > 0.3 * counts.mean()          # equally long frame windows hold comparable work
+    # a factor never reaches further back than its owner's window (what the library's local elimination relies on)
+    frame = (g.var_keys & np.uint64((1 << 48) - 1)).astype(np.int64)
+    fmin, span = int(frame[g.var_type == 0].min()), int(frame[g.var_type == 0].max() - frame[g.var_type == 0].min()) + 1
+    for r, s_ in enumerate(shards):
+        for b in s_.blocks:
+            pf = np.where(g.var_type[b.var_idx] == 0, frame[b.var_idx], 1 << 40).min(axis=1)
+            assert (np.minimum(world - 1, (pf - fmin) * world // span) >= r).all()
 
 
 def test_c_abi_exports_every_declared_symbol():

@@ -371,6 +371,7 @@ __global__ __launch_bounds__(256) void k_reduce_partial(const double* __restrict
 // ------------------------------------------------------------------------------------------
 struct PointView {
   int64_t n_point;
+  const uint8_t* chained;  // [n_point] 1: the point belongs to a chain (handled by k_chain_*), may be null
   const int32_t* pf_ptr;   // [n_point+1] incidence CSR
   const int64_t* pf_joff;  // offset of Jp (3x3 row-major) in Jbuf
   const int64_t* pf_boff;  // offset of b (3)
@@ -380,7 +381,7 @@ struct PointView {
 __global__ void k_point(PointView P, const double* const* __restrict__ Jpp, const double* __restrict__ lambda_p,
                         double* __restrict__ Cq, double* __restrict__ uq, int* __restrict__ fail_flag) {
   const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= P.n_point) return;
+  if (q >= P.n_point || (P.chained && P.chained[q])) return;
   const double* __restrict__ Jbuf = *Jpp;
   const double lambda = *lambda_p;
   double h00 = lambda, h01 = 0, h02 = 0, h11 = lambda, h12 = 0, h22 = lambda, g0 = 0, g1 = 0, g2 = 0;
@@ -420,6 +421,188 @@ __global__ void k_point(PointView P, const double* const* __restrict__ Jpp, cons
   u[2] = i20 * g0 + i21 * g1 + i22 * g2;
 }
 
+// ------------------------------------------------------------------------------------------
+// Point CHAINS (LandmarkMotionTernaryFactor couples the point of a tracklet at frame k-1
+// with its point at frame k).  The points of one tracklet form a path, so H_gg of the chain is block tridiagonal:
+//   D_i = sum Jp^T Jp + lambda I (3x3, all factor slots on point i),   O_i = sum J_i^T J_{i+1} over the link factors.
+// Block Cholesky along the chain, one lane per chain (L <= ~14 sequential 3x3 steps):
+//   B_i = O_{i-1}^T L_{i-1,i-1}^-T,   L_ii = chol(D_i - B_i B_i^T),   u_i = L_ii^-1 (g_i - B_i u_{i-1})
+// stored per point: C_i = L_ii^-T (upper, same 6-value format as a free point), B_i (3x3 row-major), u_i.
+// ------------------------------------------------------------------------------------------
+struct ChainView {
+  int64_t n_chain;
+  const int32_t* ch_ptr;    // [n_chain+1] into ch_point
+  const int32_t* ch_point;  // point index of every chain position
+  const int32_t* lk_ptr;    // [n_link+1] link j joins positions (ch_ptr[g]+i, +i+1), j = ch_ptr[g] + i - g
+  const int64_t* lk_ja;     // offset of J of the earlier point (3x3 row-major)
+  const int64_t* lk_jb;     // offset of J of the later point
+};
+
+__global__ void k_chain_factor(ChainView V, PointView P, const double* const* __restrict__ Jpp, const double* __restrict__ lambda_p,
+                               double* __restrict__ Cq, double* __restrict__ Bq, double* __restrict__ uq, int* __restrict__ fail_flag) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= V.n_chain) return;
+  const double* __restrict__ Jbuf = *Jpp;
+  const double lambda = *lambda_p;
+  double Cp[6] = {0, 0, 0, 0, 0, 0}, up[3] = {0, 0, 0};   // previous position: C = L^-T (upper), u
+  for (int pos = V.ch_ptr[g]; pos < V.ch_ptr[g + 1]; ++pos) {
+    const int64_t q = V.ch_point[pos];
+    double h[6] = {lambda, 0, 0, lambda, 0, lambda}, gq[3] = {0, 0, 0};   // h00 h01 h02 h11 h12 h22
+    for (int k = P.pf_ptr[q]; k < P.pf_ptr[q + 1]; ++k) {
+      const double* J = Jbuf + P.pf_joff[k];
+      const double* b = Jbuf + P.pf_boff[k];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const double a0 = J[r * 3], a1 = J[r * 3 + 1], a2 = J[r * 3 + 2], br = b[r];
+        h[0] += a0 * a0; h[1] += a0 * a1; h[2] += a0 * a2; h[3] += a1 * a1; h[4] += a1 * a2; h[5] += a2 * a2;
+        gq[0] += a0 * br; gq[1] += a1 * br; gq[2] += a2 * br;
+      }
+    }
+    double B[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (pos > V.ch_ptr[g]) {
+      // O^T = sum J_later^T J_earlier  (rows: this point, columns: previous point)
+      double Ot[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      const int lk = pos - 1 - (int)g;
+      for (int k = V.lk_ptr[lk]; k < V.lk_ptr[lk + 1]; ++k) {
+        const double* Ja = Jbuf + V.lk_ja[k];
+        const double* Jb = Jbuf + V.lk_jb[k];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) Ot[i * 3 + j] += Jb[r * 3 + i] * Ja[r * 3 + j];
+      }
+      // B = O^T L_prev^-T = O^T C_prev  (C upper: c00 c01 c02 c11 c12 c22)
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        B[i * 3] = Ot[i * 3] * Cp[0];
+        B[i * 3 + 1] = Ot[i * 3] * Cp[1] + Ot[i * 3 + 1] * Cp[3];
+        B[i * 3 + 2] = Ot[i * 3] * Cp[2] + Ot[i * 3 + 1] * Cp[4] + Ot[i * 3 + 2] * Cp[5];
+      }
+      // D -= B B^T,  g -= B u_prev
+      h[0] -= B[0] * B[0] + B[1] * B[1] + B[2] * B[2];
+      h[1] -= B[0] * B[3] + B[1] * B[4] + B[2] * B[5];
+      h[2] -= B[0] * B[6] + B[1] * B[7] + B[2] * B[8];
+      h[3] -= B[3] * B[3] + B[4] * B[4] + B[5] * B[5];
+      h[4] -= B[3] * B[6] + B[4] * B[7] + B[5] * B[8];
+      h[5] -= B[6] * B[6] + B[7] * B[7] + B[8] * B[8];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) gq[i] -= B[i * 3] * up[0] + B[i * 3 + 1] * up[1] + B[i * 3 + 2] * up[2];
+    }
+    bool ok = h[0] > 0.0;
+    const double l00 = sqrt(ok ? h[0] : 1.0);
+    const double l10 = h[1] / l00, l20 = h[2] / l00;
+    const double d11 = h[3] - l10 * l10;
+    ok = ok && d11 > 0.0;
+    const double l11 = sqrt(d11 > 0.0 ? d11 : 1.0);
+    const double l21 = (h[4] - l20 * l10) / l11;
+    const double d22 = h[5] - l20 * l20 - l21 * l21;
+    ok = ok && d22 > 0.0;
+    const double l22 = sqrt(d22 > 0.0 ? d22 : 1.0);
+    if (!ok) atomicMin(fail_flag, (int)q);
+    const double i00 = 1.0 / l00, i11 = 1.0 / l11, i22 = 1.0 / l22;
+    const double i10 = -l10 * i00 * i11, i21 = -l21 * i11 * i22, i20 = (l10 * l21 - l20 * l11) * i00 * i11 * i22;
+    Cp[0] = i00; Cp[1] = i10; Cp[2] = i20; Cp[3] = i11; Cp[4] = i21; Cp[5] = i22;
+    up[0] = i00 * gq[0]; up[1] = i10 * gq[0] + i11 * gq[1]; up[2] = i20 * gq[0] + i21 * gq[1] + i22 * gq[2];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Cq[6 * q + k] = Cp[k];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Bq[9 * q + k] = B[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) uq[3 * q + k] = up[k];
+  }
+}
+
+// One lane per (pose, chain) edge: W_i = sum Jc^T Jp over the pose's factor slots on chain position i, then the
+// forward recursion  Y_i = L_ii^-1 (W_i^T - B_i Y_{i-1}).  Z blocks (6x3 = Y_i^T) are written for the positions
+// first..last of the edge as consecutive "sub-edges", so that assembly / rhs / back-substitution see a chain edge as
+// a run of ordinary pose-point edges:  W H_gg^-1 W'^T = sum_i Z_i Z'_i^T.
+struct ChainEdgeView {
+  int64_t n_cedge;
+  const int32_t* ce_ptr;     // [n_cedge+1] contributions
+  const int32_t* ce_pos;     // global chain position (index into ch_point) of the contribution
+  const int64_t* ce_jc;      // offset of Jc (3x6)
+  const int64_t* ce_jp;      // offset of Jp (3x3)
+  const int32_t* ce_first;   // first global position of the edge
+  const int32_t* ce_last;    // last position of its chain (inclusive)
+  const int32_t* ce_sptr;    // [n_cedge+1] into ce_subid
+  const int32_t* ce_subid;   // edge id (row of Z) of the sub-edge at position ce_first + k
+};
+
+__global__ void k_chain_edge(ChainEdgeView E, const int32_t* __restrict__ ch_point, const double* const* __restrict__ Jpp,
+                             const double* __restrict__ Cq, const double* __restrict__ Bq, double* __restrict__ Z) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E.n_cedge) return;
+  const double* __restrict__ Jbuf = *Jpp;
+  double Yp[18];   // Y_{i-1} (3x6 row-major)
+#pragma unroll
+  for (int k = 0; k < 18; ++k) Yp[k] = 0.0;
+  int k = E.ce_ptr[e];
+  const int kend = E.ce_ptr[e + 1];
+  for (int pos = E.ce_first[e]; pos <= E.ce_last[e]; ++pos) {
+    const int64_t q = ch_point[pos];
+    double Wt[18];   // W_i^T (3x6) = sum Jp^T Jc
+#pragma unroll
+    for (int t = 0; t < 18; ++t) Wt[t] = 0.0;
+    for (; k < kend && E.ce_pos[k] == pos; ++k) {
+      const double* Jc = Jbuf + E.ce_jc[k];
+      const double* Jp = Jbuf + E.ce_jp[k];
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 6; ++j) Wt[i * 6 + j] += Jp[r * 3 + i] * Jc[r * 6 + j];
+    }
+    if (pos > E.ce_first[e]) {
+      const double* B = Bq + 9 * q;
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) Wt[i * 6 + j] -= B[i * 3] * Yp[j] + B[i * 3 + 1] * Yp[6 + j] + B[i * 3 + 2] * Yp[12 + j];
+    }
+    // Y = Linv Wt,  Linv = C^T (lower): rows (c00), (c01 c11), (c02 c12 c22)
+    const double* C = Cq + 6 * q;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const double w0 = Wt[j], w1 = Wt[6 + j], w2 = Wt[12 + j];
+      Yp[j] = C[0] * w0;
+      Yp[6 + j] = C[1] * w0 + C[3] * w1;
+      Yp[12 + j] = C[2] * w0 + C[4] * w1 + C[5] * w2;
+    }
+    double* z = Z + 18 * (int64_t)E.ce_subid[E.ce_sptr[e] + (pos - E.ce_first[e])];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) z[i * 3 + c] = Yp[c * 6 + i];
+  }
+}
+
+// back-substitution along every chain: on entry dpoint holds t_i = u_i - sum_edges Z^T delta_pose (written by
+// k_backsub_points for chained points); delta_i = L_ii^-T (t_i - B_{i+1}^T delta_{i+1}), last position first.
+__global__ void k_chain_backsub(ChainView V, const double* __restrict__ Cq, const double* __restrict__ Bq, double* __restrict__ dpoint) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= V.n_chain) return;
+  double dn[3] = {0, 0, 0};
+  const double* Bn = nullptr;
+  for (int pos = V.ch_ptr[g + 1] - 1; pos >= V.ch_ptr[g]; --pos) {
+    const int64_t q = V.ch_point[pos];
+    double t0 = dpoint[3 * q], t1 = dpoint[3 * q + 1], t2 = dpoint[3 * q + 2];
+    if (Bn) {   // B_{i+1}^T delta_{i+1}
+      t0 -= Bn[0] * dn[0] + Bn[3] * dn[1] + Bn[6] * dn[2];
+      t1 -= Bn[1] * dn[0] + Bn[4] * dn[1] + Bn[7] * dn[2];
+      t2 -= Bn[2] * dn[0] + Bn[5] * dn[1] + Bn[8] * dn[2];
+    }
+    const double* C = Cq + 6 * q;
+    dn[0] = C[0] * t0 + C[1] * t1 + C[2] * t2;
+    dn[1] = C[3] * t1 + C[4] * t2;
+    dn[2] = C[5] * t2;
+    dpoint[3 * q] = dn[0]; dpoint[3 * q + 1] = dn[1]; dpoint[3 * q + 2] = dn[2];
+    Bn = Bq + 9 * q;
+  }
+}
+
 struct EdgeView {
   int64_t n_edge;
   const int32_t* e_pose;   // elimination index of the pose
@@ -430,7 +613,7 @@ struct EdgeView {
 
 __global__ void k_edge_z(EdgeView E, const double* const* __restrict__ Jpp, const double* __restrict__ Cq, double* __restrict__ Z) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= E.n_edge) return;
+  if (e >= E.n_edge || E.e_jc[e] < 0) return;   // e_jc < 0: sub-edge of a point chain, written by k_chain_edge
   const double* __restrict__ Jbuf = *Jpp;
   const double* Jc = Jbuf + E.e_jc[e];
   const double* Jp = Jbuf + E.e_jp[e];
@@ -912,6 +1095,7 @@ struct PointEdgeView {
   int64_t n_point;
   const int32_t* qe_ptr;   // [n_point+1] edges of a point are contiguous: edge ids qe_ptr[q]..qe_ptr[q+1]-1
   const int32_t* e_pose;
+  const uint8_t* chained;  // may be null
 };
 __global__ void k_backsub_points(PointEdgeView V, const double* __restrict__ Z, const double* __restrict__ Cq,
                                  const double* __restrict__ uq, const double* __restrict__ dpose, double* __restrict__ dpoint) {
@@ -923,6 +1107,10 @@ __global__ void k_backsub_points(PointEdgeView V, const double* __restrict__ Z, 
     const double* d = dpose + 6 * (int64_t)V.e_pose[e];
 #pragma unroll
     for (int i = 0; i < 6; ++i) { s0 -= z[i * 3] * d[i]; s1 -= z[i * 3 + 1] * d[i]; s2 -= z[i * 3 + 2] * d[i]; }
+  }
+  if (V.chained && V.chained[q]) {   // k_chain_backsub finishes along the chain
+    dpoint[3 * q] = s0; dpoint[3 * q + 1] = s1; dpoint[3 * q + 2] = s2;
+    return;
   }
   const double* C = Cq + 6 * q;
   dpoint[3 * q] = C[0] * s0 + C[1] * s1 + C[2] * s2;

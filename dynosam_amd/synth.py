@@ -388,3 +388,110 @@ def make_hybrid_graph(cfg: ScenarioConfig) -> FlatGraph:
     meta = dict(cfg=cfg, gt_state=gt_state, n_static=Ns, n_dynamic=Nd, frames=K, objects=J, var_frame=var_frame_all[order],
                 factor_frame=[np.asarray(b[6], dtype=np.int64) for b in blocks])
     return FlatGraph(var_keys, var_type, var_state, out_blocks, meta)
+
+
+def make_wcme_graph(cfg: ScenarioConfig) -> FlatGraph:
+    """World-centric motion estimator graph (dynosam/src/backend/rgbd/WorldMotionEstimator.cc:151-349): one point
+    variable m_{i,k} per dynamic observation, PoseToPointFactor(X_k, m_{i,k}), LandmarkMotionTernaryFactor(m_{i,k-1},
+    m_{i,k}, H_{j,k}) with H_{j,k} the object's world motion from frame k-1 to k, BetweenFactor(H_{j,k-1}, H_{j,k};
+    Identity) smoothing, plus the static part of the HYBRID graph (odometry, static PoseToPoint, prior on X_0)."""
+    from .graph import F_LANDMARK_TERNARY
+    rng = np.random.default_rng(cfg.seed + 1000)
+    K, J, ns = cfg.frames, cfg.objects, cfg.noise_scale
+    frames = np.arange(K)
+    xi_cam = se3_log(rzryrx(0.003, 0.002, 0.0)[None], np.array([[0.014, 0.038, 0.0]]))[0]
+    X_gt = se3_exp(frames[:, None] * xi_cam[None])
+    rel_gt = compose(inverse((X_gt[0][:-1], X_gt[1][:-1])), (X_gt[0][1:], X_gt[1][1:]))
+    rel_meas = _perturb(rng, rel_gt, cfg.odom_sigma_rot * ns, cfg.odom_sigma_trans * ns)
+    Xi = [(X_gt[0][0], X_gt[1][0])]
+    for k in range(1, K):
+        Xi.append((Xi[-1][0] @ rel_meas[0][k - 1], Xi[-1][0] @ rel_meas[1][k - 1] + Xi[-1][1]))
+    X_init = (np.stack([x[0] for x in Xi]), np.stack([x[1] for x in Xi]))
+    # objects: constant world motion M_j per frame, pose L_{j,k} = M_j^k L_{j,0}
+    obj_xi = np.concatenate([rng.normal(0, 0.01, (J, 3)), rng.normal(0, 0.15, (J, 3))], -1)
+    ang, rad = rng.uniform(-0.6, 0.6, J), rng.uniform(5.0, 30.0, J)
+    L0 = (so3_exp(rng.normal(0, 0.3, (J, 3))), np.stack([rad * np.sin(ang), rng.uniform(-1, 1, J), rad * np.cos(ang)], -1))
+    keys, vtype, state, vframe = [], [], [], []
+    pad = lambda p: np.concatenate([p, np.zeros((len(p), 9))], -1)
+    # H_{j,k}, k = 1..K-1 (ground truth = M_j); initial guess perturbed
+    Hk, Hgt, Hinit = [], [], []
+    for j in range(J):
+        M = se3_exp(obj_xi[j][None])
+        Mk = (np.repeat(M[0], K - 1, 0), np.repeat(M[1], K - 1, 0))
+        Hk += [S.ObjectMotionSymbol(j + 1, int(k)) for k in range(1, K)]
+        Hgt.append(to12(Mk))
+        Hinit.append(to12(_perturb(rng, Mk, cfg.motion_init_sigma_rot * ns, cfg.motion_init_sigma_trans * ns)))
+        vframe += list(range(1, K))
+    Hgt, Hinit = np.concatenate(Hgt), np.concatenate(Hinit)
+    # static tracks
+    Ns = cfg.static_points
+    s_len = rng.integers(cfg.static_track[0], cfg.static_track[1] + 1, Ns)
+    s_birth = rng.integers(0, max(1, K - cfg.static_track[0] + 1), Ns)
+    s_len = np.minimum(s_len, K - s_birth)
+    depth = rng.uniform(2.0, 45.0, Ns)
+    p_cam = np.concatenate([np.stack([rng.uniform(-0.55, 0.55, Ns), rng.uniform(-0.4, 0.4, Ns)], -1) * depth[:, None], depth[:, None]], -1)
+    mid = np.minimum(s_birth + s_len // 2, K - 1)
+    l_gt = act((X_gt[0][mid], X_gt[1][mid]), p_cam)
+    so_track = np.repeat(np.arange(Ns), s_len)
+    so_frame = np.concatenate([np.arange(b, b + n) for b, n in zip(s_birth, s_len)])
+    z_gt = act(inverse((X_gt[0][so_frame], X_gt[1][so_frame])), l_gt[so_track])
+    zc = np.maximum(np.abs(z_gt[:, 2]), 0.5)
+    s_sig = np.stack([cfg.static_sigma_xy * zc, cfg.static_sigma_xy * zc, cfg.static_sigma_z * zc * zc], -1)
+    z_s = z_gt + rng.normal(0, 1, z_gt.shape) * s_sig * ns
+    first_obs = np.concatenate([[0], np.cumsum(s_len)[:-1]])
+    l_init = act((X_init[0][s_birth], X_init[1][s_birth]), z_s[first_obs])
+    # dynamic tracks: one point variable per observation
+    Nd = J * cfg.dynamic_points_per_object
+    d_obj = np.repeat(np.arange(J), cfg.dynamic_points_per_object)
+    d_len = rng.integers(cfg.dynamic_track[0], cfg.dynamic_track[1] + 1, Nd)
+    d_birth = (rng.uniform(0, 1, Nd) * max(1, K - cfg.dynamic_track[0] + 1)).astype(int)
+    d_len = np.minimum(d_len, K - d_birth)
+    m_obj = rng.normal(0, 0.5, (Nd, 3))
+    do_track = np.repeat(np.arange(Nd), d_len)
+    do_frame = np.concatenate([np.arange(b, b + n) for b, n in zip(d_birth, d_len)])
+    pw = np.zeros((len(do_track), 3))
+    for j in range(J):
+        sel = np.nonzero(d_obj[do_track] == j)[0]
+        Mk = se3_exp(do_frame[sel][:, None] * obj_xi[j][None])
+        Lk = compose(Mk, (np.repeat(L0[0][j][None], len(sel), 0), np.repeat(L0[1][j][None], len(sel), 0)))
+        pw[sel] = act(Lk, m_obj[do_track[sel]])
+    z_d = act(inverse((X_gt[0][do_frame], X_gt[1][do_frame])), pw) + rng.normal(0, cfg.dynamic_sigma, pw.shape) * ns
+    m_init = act((X_init[0][do_frame], X_init[1][do_frame]), z_d)     # back-projection through the initial camera pose
+    m_keys = [S.DynamicLandmarkSymbol(int(f), int(Ns + t)) for t, f in zip(do_track, do_frame)]
+    # ---- variables, ascending key order
+    X_keys = [S.CameraPoseSymbol(int(k)) for k in range(K)]
+    l_keys = [S.StaticLandmarkSymbol(int(i)) for i in range(Ns)]
+    all_keys = np.array(Hk + X_keys + l_keys + m_keys, dtype=np.uint64)
+    all_type = np.array([VAR_POSE3] * (len(Hk) + K) + [VAR_POINT3] * (Ns + len(m_keys)), dtype=np.uint8)
+    all_state = np.concatenate([Hinit, to12(X_init), pad(l_init), pad(m_init)], 0)
+    gt_state = np.concatenate([Hgt, to12(X_gt), pad(l_gt), pad(pw)], 0)
+    order = np.argsort(all_keys, kind="stable")
+    inv = np.empty_like(order); inv[order] = np.arange(len(order))
+    nH = len(Hk)
+    Hvar, Xvar = inv[np.arange(nH)], inv[nH + np.arange(K)]
+    lvar, mvar = inv[nH + K + np.arange(Ns)], inv[nH + K + Ns + np.arange(len(m_keys))]
+    iso6 = lambda sr, st, n: np.tile(np.array([sr] * 3 + [st] * 3), (n, 1))
+    blocks = []
+    blocks.append(FactorBlock(F_PRIOR_POSE3, [0], Xvar[:1, None], to12((X_gt[0][:1], X_gt[1][:1])), iso6(cfg.prior_sigma, cfg.prior_sigma, 1)))
+    blocks.append(FactorBlock(F_BETWEEN_POSE3, np.arange(K - 1), np.stack([Xvar[:-1], Xvar[1:]], -1), to12(rel_meas), iso6(cfg.odom_sigma_rot, cfg.odom_sigma_trans, K - 1)))
+    Rs = np.zeros((len(so_track), 9)); Rs[:, 0], Rs[:, 4], Rs[:, 8] = 1.0 / s_sig[:, 0], 1.0 / s_sig[:, 1], 1.0 / s_sig[:, 2]
+    hk = lambda n: np.full(n, cfg.k_huber) if cfg.robust else None
+    blocks.append(FactorBlock(F_POSE_TO_POINT, np.arange(len(so_track)), np.stack([Xvar[so_frame], lvar[so_track]], -1), z_s, Rs, hk(len(so_track))))
+    Rd = np.zeros((len(do_track), 9)); Rd[:, 0] = Rd[:, 4] = Rd[:, 8] = 1.0 / cfg.dynamic_sigma
+    blocks.append(FactorBlock(F_POSE_TO_POINT, np.arange(len(do_track)), np.stack([Xvar[do_frame], mvar], -1), z_d, Rd, hk(len(do_track))))
+    # ternary: consecutive observations of a tracklet, motion H_{j,k} of the later frame
+    obs_idx = np.arange(len(do_track))
+    later = obs_idx[1:][do_track[1:] == do_track[:-1]]
+    hrow = d_obj[do_track[later]] * (K - 1) + (do_frame[later] - 1)
+    Rt = np.zeros((len(later), 9)); Rt[:, 0] = Rt[:, 4] = Rt[:, 8] = 1.0 / 0.01     # motion_ternary_factor_noise_sigma (BackendParams.cc:38)
+    blocks.append(FactorBlock(F_LANDMARK_TERNARY, np.arange(len(later)), np.stack([mvar[later - 1], mvar[later], Hvar[hrow]], -1), np.zeros((len(later), 0)), Rt, hk(len(later))))
+    # constant-motion smoothing between consecutive object motions (WorldMotionEstimator.cc:341-343)
+    sm = np.array([[Hvar[j * (K - 1) + k - 1], Hvar[j * (K - 1) + k]] for j in range(J) for k in range(1, K - 1)])
+    ident = np.tile(to12((np.eye(3)[None], np.zeros((1, 3)))), (len(sm), 1))
+    blocks.append(FactorBlock(F_BETWEEN_POSE3, np.arange(len(sm)), sm, ident, iso6(cfg.smoothing_sigma_rot, cfg.smoothing_sigma_trans, len(sm))))
+    # remap to sorted variable order and give every factor a unique slot
+    out, s0 = [], 0
+    for b in blocks:
+        out.append(FactorBlock(b.type, np.arange(s0, s0 + b.count), b.var_idx, b.meas, b.noise, b.huber_k, b.consts))
+        s0 += b.count
+    return FlatGraph(all_keys[order], all_type[order], all_state[order], out, dict(cfg=cfg, gt_state=gt_state[order], frames=K, objects=J))

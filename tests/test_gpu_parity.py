@@ -112,11 +112,10 @@ def test_every_factor_class_linearizes_like_the_oracle(lib_loaded, oracle):
         assert np.abs(b[f] - br[f]).max() <= 1e-11 * max(1.0, np.abs(br[f]).max()), f
     assert np.allclose(e, er, rtol=1e-11, atol=1e-13)
     assert abs(c.error() - og.error()) <= 1e-11 * og.error()
-    # point-point coupling (LandmarkMotionTernary) is linearised but its Schur path is not built yet
-    from dynosam_amd import _lib
-    with pytest.raises(_lib.DynoError) as ei:
-        c.optimize()
-    assert ei.value.status == 5
+    # the ternary factor couples two points: they are eliminated as a chain (block-tridiagonal Schur complement)
+    d, dec = c.solve_damped(1e-3)
+    bad, dr, decr = og.solve_damped(1e-3)
+    assert bad == 0 and np.abs(d - dr).max() <= 1e-6 * max(1.0, np.abs(dr).max())
 
 
 def test_damped_solve_matches_oracle(lib_loaded, oracle):
@@ -278,3 +277,42 @@ def test_values_roundtrip_and_reupload(lib_loaded):
     c.optimize()
     c.set_values(g.var_state)
     assert c.error() == e0
+
+
+# ---- WCME formulation: LandmarkMotionTernaryFactor couples the per-frame points of a tracklet ----
+def wcme(frames=10, **kw):
+    base = dict(static_points=20, dynamic_points_per_object=8, static_track=(3, 6), dynamic_track=(3, 7))
+    base.update(kw)
+    return synth.make_wcme_graph(synth.config(1, frames=frames, **base))
+
+
+def test_wcme_damped_solve_matches_dense_oracle(lib_loaded, oracle):
+    """point chains eliminated by the block-tridiagonal Schur complement == the oracle's dense full-system solve"""
+    for g in (wcme(), wcme(frames=24, objects=2, static_points=60, dynamic_points_per_object=20, dynamic_track=(2, 9))):
+        c, og = ctx_for(g), oracle.OracleGraph(g)
+        assert abs(c.error() - og.error()) <= 1e-12 * og.error()
+        for lam in (1e-5, 1e-2):
+            d, dec = c.solve_damped(lam)
+            bad, dr, decr = og.solve_damped(lam)
+            assert bad == 0
+            assert np.abs(d - dr).max() <= 1e-6 * max(1.0, np.abs(dr).max())
+            assert abs(dec - decr) <= 1e-6 * abs(decr)
+
+
+def test_wcme_lm_trace_matches_oracle(lib_loaded, oracle):
+    g = wcme(frames=16, objects=2, static_points=40, dynamic_points_per_object=12)
+    c, og = ctx_for(g), oracle.OracleGraph(g)
+    rep = c.optimize()
+    rr, _ = og.optimize()
+    assert rep.iterations == rr.iterations and rep.inner_iterations == rr.inner_iterations
+    assert [rep.trace_accepted[i] for i in range(rep.trace_len)] == [rr.trace_accepted[i] for i in range(rr.trace_len)]
+    assert abs(rep.error_after - rr.error_after) <= 1e-6 * rr.error_after
+    assert np.abs(c.values() - og.state()).max() <= 1e-5
+
+
+def test_wcme_noiseless_graph_is_a_fixed_point(lib_loaded):
+    g = wcme(noise_scale=0.0)
+    c = ctx_for(g.with_state(g.meta["gt_state"]))
+    assert c.error() < 1e-20
+    d, _ = c.solve_damped(1e-5)
+    assert np.abs(d).max() < 1e-9

@@ -269,6 +269,76 @@ __global__ void k_linearize_smooth(BlockView B, const double* __restrict__ poses
   }
 }
 
+// LandmarkMotionPoseFactor / LandmarkPoseSmoothingFactor: the reference takes ALL their Jacobians by
+// gtsam::numericalDerivative4x / 3x (central difference on the manifold, delta = 1e-5); one lane per Jacobian column
+// (18 columns for both classes), exactly as k_linearize_smooth does for HybridSmoothingFactor.
+template <int T>
+__device__ __forceinline__ void res_numeric(const Pose* P, const double (*pt)[3], double* e) {
+  if constexpr (T == T_LMP) res_lmp(pt[0], pt[1], P[2], P[3], e);
+  else res_lps(P[0], P[1], P[2], e);
+}
+template <int T>
+__global__ void k_linearize_numeric(BlockView B, const double* __restrict__ poses, const double* __restrict__ points, double* __restrict__ Jbuf,
+                                    double* __restrict__ err_out) {
+  constexpr int D = f_dim(T), AR = f_arity(T);
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i = gid / 18;
+  const int c = (int)(gid % 18);
+  if (i >= B.count) return;
+  int vv = 0, j = c;
+#pragma unroll
+  for (int s = 0; s < AR; ++s) { if (j >= f_slot_width(T, s) && s + 1 < AR && vv == s) { j -= f_slot_width(T, s); vv = s + 1; } }
+  const int32_t* v = B.vidx + i * AR;
+  Pose P[F_MAX_ARITY];
+  double pt[F_MAX_ARITY][3];
+#pragma unroll
+  for (int s = 0; s < AR; ++s) {
+    if (f_slot_is_point(T, s)) { const double* x = points + 3 * (int64_t)v[s]; pt[s][0] = x[0]; pt[s][1] = x[1]; pt[s][2] = x[2]; }
+    else P[s] = load_pose(poses + 12 * (int64_t)v[s]);
+  }
+  double e[D], rp[D], rm[D];
+  res_numeric<T>(P, pt, e);
+  const double delta = 1e-5, factor = 1.0 / (2.0 * delta);
+  if (f_slot_is_point(T, vv >= AR ? 0 : vv) ) {
+    const double keep = pt[vv][j];
+    pt[vv][j] = keep + delta; res_numeric<T>(P, pt, rp);
+    pt[vv][j] = keep - delta; res_numeric<T>(P, pt, rm);
+    pt[vv][j] = keep;
+  } else {
+    double dx[6] = {0, 0, 0, 0, 0, 0};
+    const Pose keep = P[vv];
+    dx[j] = delta;  P[vv] = retract(keep, dx); res_numeric<T>(P, pt, rp);
+    dx[j] = -delta; P[vv] = retract(keep, dx); res_numeric<T>(P, pt, rm);
+    P[vv] = keep;
+  }
+  double col[D], we[D];
+#pragma unroll
+  for (int a = 0; a < D; ++a) col[a] = ((rp[a] - e[a]) - (rm[a] - e[a])) * factor;
+  double sq = 0, wcol[D];
+  if constexpr (D == 3) {
+    const double* Rn = B.noise + 9 * i;
+    sq = whiten3(Rn, e, we);
+    mat3_vec(Rn, col, wcol);
+  } else {
+    const double* sg = B.noise + 6 * i;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) { const double is = 1.0 / sg[a]; we[a] = e[a] * is; wcol[a] = col[a] * is; sq += we[a] * we[a]; }
+  }
+  const double hk = B.huber ? B.huber[i] : 0.0;
+  const double w = hk > 0.0 ? sqrt(huber_weight(hk, sqrt(sq))) : 1.0;
+  double* rec = Jbuf + B.rec0 + i * f_rec(T);
+  int off = 0, wid = 6;
+#pragma unroll
+  for (int s = 0; s < AR; ++s) if (s == vv) { off = f_slot_off(T, s); wid = f_slot_width(T, s); }
+#pragma unroll
+  for (int a = 0; a < D; ++a) rec[off + a * wid + j] = w * wcol[a];
+  if (c == 0) {
+#pragma unroll
+    for (int a = 0; a < D; ++a) rec[f_b_off(T) + a] = -w * we[a];
+    if (err_out) err_out[B.f0 + i] = loss_from_sq(sq, hk);
+  }
+}
+
 // nonlinear error only (trial values), per type
 template <int T>
 __global__ void k_error(BlockView B, const double* __restrict__ poses, const double* __restrict__ points,
@@ -288,12 +358,14 @@ __global__ void k_error(BlockView B, const double* __restrict__ poses, const dou
     if constexpr (T == T_PTP) res_ptp(load_pose(poses + 12 * (int64_t)v[0]), points + 3 * (int64_t)v[1], B.meas + 3 * i, e, q);
     else if constexpr (T == T_STEREO) res_stereo(load_pose(poses + 12 * (int64_t)v[0]), points + 3 * (int64_t)v[1], B.meas + 3 * i, B.consts + 6 * i, e, q);
     else if constexpr (T == T_HM) res_hm(load_pose(poses + 12 * (int64_t)v[0]), load_pose(poses + 12 * (int64_t)v[1]), load_pose(B.consts + 12 * i), points + 3 * (int64_t)v[2], B.meas + 3 * i, e, q, p);
+    else if constexpr (T == T_LMP) res_lmp(points + 3 * (int64_t)v[0], points + 3 * (int64_t)v[1], load_pose(poses + 12 * (int64_t)v[2]), load_pose(poses + 12 * (int64_t)v[3]), e);
     else res_ternary(points + 3 * (int64_t)v[0], points + 3 * (int64_t)v[1], load_pose(poses + 12 * (int64_t)v[2]), e, q);
     sq = whiten3(B.noise + 9 * i, e, we);
   } else {
     double e[6];
     if constexpr (T == T_PRIOR) res_prior(load_pose(poses + 12 * (int64_t)v[0]), load_pose(B.meas + 12 * i), e);
     else if constexpr (T == T_BETWEEN) res_between(load_pose(poses + 12 * (int64_t)v[0]), load_pose(poses + 12 * (int64_t)v[1]), load_pose(B.meas + 12 * i), e, nullptr);
+    else if constexpr (T == T_LPS) res_lps(load_pose(poses + 12 * (int64_t)v[0]), load_pose(poses + 12 * (int64_t)v[1]), load_pose(poses + 12 * (int64_t)v[2]), e);
     else res_smooth(load_pose(poses + 12 * (int64_t)v[0]), load_pose(poses + 12 * (int64_t)v[1]), load_pose(poses + 12 * (int64_t)v[2]), load_pose(B.consts + 12 * i), e);
     const double* sg = B.noise + 6 * i;
 #pragma unroll

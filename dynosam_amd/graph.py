@@ -23,6 +23,8 @@ F_HYBRID_MOTION = 3
 F_HYBRID_SMOOTHING = 4
 F_LANDMARK_TERNARY = 5
 F_STEREO_POINT = 6
+F_LANDMARK_MOTION_POSE = 7
+F_LANDMARK_POSE_SMOOTHING = 8
 F_LINEARIZED = 16   # flag: gtsam::LinearContainerFactor of a factor of the class in the low bits
 
 F_NAMES = {
@@ -33,6 +35,8 @@ F_NAMES = {
     F_HYBRID_SMOOTHING: "HybridSmoothingFactor",
     F_LANDMARK_TERNARY: "LandmarkMotionTernaryFactor",
     F_STEREO_POINT: "GenericStereoFactor",
+    F_LANDMARK_MOTION_POSE: "LandmarkMotionPoseFactor",
+    F_LANDMARK_POSE_SMOOTHING: "LandmarkPoseSmoothingFactor",
 }
 #                 arity dim meas noise const
 F_LAYOUT = {
@@ -43,6 +47,8 @@ F_LAYOUT = {
     F_HYBRID_SMOOTHING: (3, 6, 0, 6, 12),
     F_LANDMARK_TERNARY: (3, 3, 0, 9, 0),
     F_STEREO_POINT: (2, 3, 3, 9, 6),
+    F_LANDMARK_MOTION_POSE: (4, 3, 0, 9, 0),
+    F_LANDMARK_POSE_SMOOTHING: (3, 6, 0, 6, 0),
 }
 
 
@@ -53,7 +59,8 @@ def _lin_layout(base):
 
 
 SLOT_WIDTHS = {F_PRIOR_POSE3: (6,), F_BETWEEN_POSE3: (6, 6), F_POSE_TO_POINT: (6, 3), F_HYBRID_MOTION: (6, 6, 3),
-               F_HYBRID_SMOOTHING: (6, 6, 6), F_LANDMARK_TERNARY: (3, 3, 6), F_STEREO_POINT: (6, 3)}
+               F_HYBRID_SMOOTHING: (6, 6, 6), F_LANDMARK_TERNARY: (3, 3, 6), F_STEREO_POINT: (6, 3),
+               F_LANDMARK_MOTION_POSE: (3, 3, 6, 6), F_LANDMARK_POSE_SMOOTHING: (6, 6, 6)}
 for _b in list(SLOT_WIDTHS):
     F_LAYOUT[_b | F_LINEARIZED] = _lin_layout(_b)
     SLOT_WIDTHS[_b | F_LINEARIZED] = SLOT_WIDTHS[_b]

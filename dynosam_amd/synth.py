@@ -494,4 +494,57 @@ def make_wcme_graph(cfg: ScenarioConfig) -> FlatGraph:
     for b in blocks:
         out.append(FactorBlock(b.type, np.arange(s0, s0 + b.count), b.var_idx, b.meas, b.noise, b.huber_k, b.consts))
         s0 += b.count
-    return FlatGraph(all_keys[order], all_type[order], all_state[order], out, dict(cfg=cfg, gt_state=gt_state[order], frames=K, objects=J))
+    return FlatGraph(all_keys[order], all_type[order], all_state[order], out,
+                     dict(cfg=cfg, gt_state=gt_state[order], frames=K, objects=J, obj_xi=obj_xi, L0=L0))
+
+
+def make_wcpe_graph(cfg: ScenarioConfig) -> FlatGraph:
+    """World-centric pose estimator graph (dynosam/src/backend/rgbd/WorldPoseEstimator.cc:100-312): object POSES L_{j,k}
+    are the variables; LandmarkMotionPoseFactor(m_{i,k-1}, m_{i,k}, L_{j,k-1}, L_{j,k}) per consecutive observation
+    pair, LandmarkPoseSmoothingFactor(L_{k-2}, L_{k-1}, L_k) per object, PoseToPointFactor(X_k, m_{i,k}) per dynamic
+    observation, plus the static part; a prior on every object's first pose fixes its gauge."""
+    from .graph import F_LANDMARK_MOTION_POSE, F_LANDMARK_POSE_SMOOTHING
+    g = make_wcme_graph(cfg)          # same scenario, same random draws: reuse cameras, statics, per-frame points
+    rng = np.random.default_rng(cfg.seed + 2000)
+    K, J, ns = cfg.frames, cfg.objects, cfg.noise_scale
+    obj_xi, L0 = g.meta["obj_xi"], g.meta["L0"]
+    is_H = np.array([S.symbol_chr(int(k)) == S.kObjectMotionSymbolChar for k in g.var_keys])
+    keep = ~is_H
+    old_idx = np.nonzero(keep)[0]
+    Lk, Lgt, Linit, Lf = [], [], [], []
+    for j in range(J):
+        Mk = se3_exp(np.arange(K)[:, None] * obj_xi[j][None])
+        Lj = compose(Mk, (np.repeat(L0[0][j][None], K, 0), np.repeat(L0[1][j][None], K, 0)))
+        Lk += [S.ObjectPoseSymbol(j + 1, int(k)) for k in range(K)]
+        Lgt.append(to12(Lj))
+        Li = _perturb(rng, Lj, cfg.motion_init_sigma_rot * ns, cfg.motion_init_sigma_trans * ns)
+        Linit.append(to12(Li))
+    Lgt, Linit = np.concatenate(Lgt), np.concatenate(Linit)
+    keys = np.concatenate([g.var_keys[keep], np.array(Lk, dtype=np.uint64)])
+    vtype = np.concatenate([g.var_type[keep], np.zeros(len(Lk), np.uint8)])
+    state = np.concatenate([g.var_state[keep], Linit])
+    gt = np.concatenate([g.meta["gt_state"][keep], Lgt])
+    order = np.argsort(keys, kind="stable")
+    inv = np.empty_like(order); inv[order] = np.arange(len(order))
+    remap = -np.ones(g.n_vars, int); remap[old_idx] = inv[np.arange(len(old_idx))]
+    Lvar = inv[len(old_idx) + np.arange(len(Lk))].reshape(J, K)
+    frame_of = (g.var_keys & np.uint64((1 << 48) - 1)).astype(np.int64)
+    label_of = ((g.var_keys >> np.uint64(48)) & np.uint64(0xFF)).astype(np.int64)
+    blocks, s0 = [], 0
+    iso6 = lambda sr, st, n: np.tile(np.array([sr] * 3 + [st] * 3), (n, 1))
+    for b in g.blocks:
+        if b.type == 5:      # ternary (m_{k-1}, m_k, H_{j,k}) -> LandmarkMotionPose (m_{k-1}, m_k, L_{j,k-1}, L_{j,k})
+            hv = b.var_idx[:, 2]
+            j, k = label_of[hv] - ord("0") - 1, frame_of[hv]
+            var = np.stack([remap[b.var_idx[:, 0]], remap[b.var_idx[:, 1]], Lvar[j, k - 1], Lvar[j, k]], -1)
+            blocks.append(FactorBlock(F_LANDMARK_MOTION_POSE, np.arange(s0, s0 + b.count), var, np.zeros((b.count, 0)), b.noise, b.huber_k))
+        elif b.type == 1 and is_H[b.var_idx[0, 0]]:
+            continue          # the H-H smoothing of WCME is replaced below
+        else:
+            blocks.append(FactorBlock(b.type, np.arange(s0, s0 + b.count), remap[b.var_idx], b.meas, b.noise, b.huber_k, b.consts))
+        s0 += b.count
+    sm = np.array([[Lvar[j, k - 2], Lvar[j, k - 1], Lvar[j, k]] for j in range(J) for k in range(2, K)])
+    blocks.append(FactorBlock(F_LANDMARK_POSE_SMOOTHING, np.arange(s0, s0 + len(sm)), sm, np.zeros((len(sm), 0)), iso6(cfg.smoothing_sigma_rot, cfg.smoothing_sigma_trans, len(sm))))
+    s0 += len(sm)
+    blocks.append(FactorBlock(F_PRIOR_POSE3, np.arange(s0, s0 + J), Lvar[:, :1], Lgt.reshape(J, K, 12)[:, 0], iso6(0.1, 0.1, J)))
+    return FlatGraph(keys[order], vtype[order], state[order], blocks, dict(cfg=cfg, gt_state=gt[order], frames=K, objects=J))

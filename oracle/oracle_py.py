@@ -112,7 +112,7 @@ class OracleGraph:
 
     def linearize(self):
         nf = self.g.n_factors
-        J = np.zeros((nf, 6, 18))
+        J = np.zeros((nf, 6, 24))
         b = np.zeros((nf, 6))
         e = np.zeros(nf)
         lib().orc_linearize(self.h, _p(J), _p(b), _p(e))
@@ -133,12 +133,12 @@ class OracleGraph:
 
 def eval_factor(ftype, states, meas=None, consts=None, want_J=True):
     """states: list of 12-vectors (points padded). returns (e[6], J[6,18] or None)."""
-    x = np.zeros(36)
+    x = np.zeros(48)
     for i, s in enumerate(states):
         s = np.asarray(s, dtype=np.float64).reshape(-1)
         x[12 * i:12 * i + s.size] = s
     e = np.zeros(6)
-    J = np.zeros((6, 18)) if want_J else None
+    J = np.zeros((6, 24)) if want_J else None
     m = _a(meas if meas is not None else [], 12)
     c = _a(consts if consts is not None else [], 12)
     lib().orc_eval_factor(int(ftype), _p(x), _p(m), _p(c), _p(e), _p(J))

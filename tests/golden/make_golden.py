@@ -36,7 +36,7 @@ def make(name, kw):
         error_before=r.error_before, error_after=r.error_after, iterations=r.iterations,
         inner_iterations=r.inner_iterations, trace_lambda=np.array(r.trace_lambda[:n]),
         trace_error=np.array(r.trace_error[:n]), trace_accepted=np.array(r.trace_accepted[:n]),
-        final_state=og.state(), J_head=J[:64], b_head=b[:64], err_factors=e, delta_1e5=delta, lin_decrease_1e5=dec)
+        final_state=og.state(), J_head=J[:64, :, :18], b_head=b[:64], err_factors=e, delta_1e5=delta, lin_decrease_1e5=dec)
     print(name, g.n_vars, g.n_factors, r.iterations, r.error_before, r.error_after)
 
 

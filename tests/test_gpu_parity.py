@@ -57,7 +57,7 @@ def test_error_and_linearize_match_oracle(lib_loaded, oracle):
     f = 0
     for blk in g.blocks:
         ar, d = G.F_LAYOUT[blk.type][0], G.F_LAYOUT[blk.type][1]
-        mask = np.ones((6, 18), bool)
+        mask = np.ones((6, 24), bool)
         for s_ in range(ar):
             w = 3 if g.var_type[blk.var_idx[0, s_]] == 1 else 6
             mask[:d, 6 * s_:6 * s_ + w] = False
@@ -153,7 +153,8 @@ def test_lm_matches_golden_fixture(lib_loaded, name):
     z = np.load(os.path.join(HERE, "golden", name + ".npz"))
     c = ctx_for(g)
     J, b, e = c.linearize()
-    assert np.abs(J[:64] - z["J_head"]).max() <= 1e-11 * np.abs(z["J_head"]).max()
+    # fixtures predate the 4-variable factor classes: 6x18 slabs (three variable slots); the fourth slot must be empty here
+    assert np.abs(J[:64, :, :18] - z["J_head"]).max() <= 1e-11 * np.abs(z["J_head"]).max() and not J[:64, :, 18:].any()
     assert np.abs(e - z["err_factors"]).max() <= 1e-11 * np.abs(z["err_factors"]).max()
     d, dec = c.solve_damped(1e-5)
     assert np.abs(d - z["delta_1e5"]).max() <= 1e-6 * max(1.0, np.abs(z["delta_1e5"]).max())
@@ -316,3 +317,36 @@ def test_wcme_noiseless_graph_is_a_fixed_point(lib_loaded):
     assert c.error() < 1e-20
     d, _ = c.solve_damped(1e-5)
     assert np.abs(d).max() < 1e-9
+
+
+# ---- WCPE formulation: LandmarkMotionPoseFactor (4 variables, 2 of them points) and
+# LandmarkPoseSmoothingFactor, both with the reference's numerical Jacobians (central difference, delta 1e-5) ----
+def wcpe(frames=10, **kw):
+    base = dict(static_points=20, dynamic_points_per_object=8, static_track=(3, 6), dynamic_track=(3, 7))
+    base.update(kw)
+    return synth.make_wcpe_graph(synth.config(1, frames=frames, **base))
+
+
+def test_wcpe_linearisation_matches_oracle(lib_loaded, oracle):
+    g = wcpe()
+    c, og = ctx_for(g), oracle.OracleGraph(g)
+    assert abs(c.error() - og.error()) <= 1e-12 * og.error()
+    J, b, e = c.linearize()
+    Jr, br, er = og.linearize()
+    # numerical Jacobians amplify rounding differences by 1/(2 delta) = 5e4
+    assert np.abs(J - Jr).max() <= 1e-9 * np.abs(Jr).max()
+    assert np.abs(b - br).max() <= 1e-11 * max(1.0, np.abs(br).max())
+    assert np.abs(e - er).max() <= 1e-11 * max(1.0, np.abs(er).max())
+
+
+def test_wcpe_solve_and_lm_match_oracle(lib_loaded, oracle):
+    g = wcpe(frames=14, objects=2, static_points=40, dynamic_points_per_object=12)
+    c, og = ctx_for(g), oracle.OracleGraph(g)
+    d, dec = c.solve_damped(1e-3)
+    bad, dr, decr = og.solve_damped(1e-3)
+    assert bad == 0 and np.abs(d - dr).max() <= 1e-6 * max(1.0, np.abs(dr).max()) and abs(dec - decr) <= 1e-6 * abs(decr)
+    rep = c.optimize()
+    rr, _ = og.optimize()
+    assert rep.iterations == rr.iterations and rep.inner_iterations == rr.inner_iterations
+    assert abs(rep.error_after - rr.error_after) <= 1e-6 * rr.error_after
+    assert np.abs(c.values() - og.state()).max() <= 1e-5

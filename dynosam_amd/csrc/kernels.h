@@ -35,6 +35,15 @@ struct BlockView {
   int64_t f0;            // global factor index of the block's first factor
 };
 
+// out(3 x C) = D(3x3) * J(3 x C)
+template <int C>
+__device__ __forceinline__ void mat_dq(const double* D, const double* J, double* out) {
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < C; ++b) out[a * C + b] = D[a * 3] * J[b] + D[a * 3 + 1] * J[C + b] + D[a * 3 + 2] * J[2 * C + b];
+}
+
 // compute record of factor i of type T into r[f_rec(T)]; returns robust-aware error of the factor
 template <int T>
 __device__ __forceinline__ double linearize_one(const BlockView& B, int64_t i, const double* __restrict__ poses,
@@ -99,10 +108,11 @@ __device__ __forceinline__ double linearize_one(const BlockView& B, int64_t i, c
     whiten3_mat<3>(Rn, Jl, w, r + 18);
     r[27] = -w * we[0]; r[28] = -w * we[1]; r[29] = -w * we[2];
     return loss_from_sq(sq, hk);
-  } else if constexpr (T == T_HM) {
+  } else if constexpr (T == T_HM || T == T_SHM) {
     const Pose X = load_pose(poses + 12 * (int64_t)v[0]);
     const Pose E = load_pose(poses + 12 * (int64_t)v[1]);
-    const Pose L = load_pose(B.consts + 12 * i);
+    const double* cst = B.consts + (int64_t)i * f_const(T);
+    const Pose L = load_pose(cst);
     const double* m = points + 3 * (int64_t)v[2];
     const double* z = B.meas + 3 * i;
     const double* Rn = B.noise + 9 * i;
@@ -123,6 +133,34 @@ __device__ __forceinline__ double linearize_one(const BlockView& B, int64_t i, c
         JE[a * 6 + 3 + b] = M[a * 3 + b];
       }
     mat3_mul(M, L.R, Jm);
+    if constexpr (T == T_SHM) {
+      // StereoHybridMotionFactor (HybridFormulationFactors.cc:213-260): camera_.project2 of the camera-frame point p;
+      // StereoCheiralityException (p.z <= 0) -> error = 2 fx, zero Jacobians
+      const double* K = cst + 12;   // fx fy s u0 v0 b
+      if (p[2] <= 0.0) {
+        e[0] = e[1] = e[2] = 2.0 * K[0];
+#pragma unroll
+        for (int a = 0; a < 18; ++a) { JX[a] = 0; JE[a] = 0; }
+#pragma unroll
+        for (int a = 0; a < 9; ++a) Jm[a] = 0;
+      } else {
+        const double iz = 1.0 / p[2];
+        e[0] = K[3] + iz * K[0] * p[0] - z[0];
+        e[1] = K[3] + iz * K[0] * (p[0] - K[5]) - z[1];
+        e[2] = K[4] + iz * K[1] * p[1] - z[2];
+        const double Dq[9] = {K[0] * iz, 0, -K[0] * p[0] * iz * iz, K[0] * iz, 0, -K[0] * (p[0] - K[5]) * iz * iz, 0, K[1] * iz, -K[1] * p[1] * iz * iz};
+        double t6[18], t3[9];
+        mat_dq<6>(Dq, JX, t6);
+#pragma unroll
+        for (int a = 0; a < 18; ++a) JX[a] = t6[a];
+        mat_dq<6>(Dq, JE, t6);
+#pragma unroll
+        for (int a = 0; a < 18; ++a) JE[a] = t6[a];
+        mat_dq<3>(Dq, Jm, t3);
+#pragma unroll
+        for (int a = 0; a < 9; ++a) Jm[a] = t3[a];
+      }
+    }
     double we[3];
     const double sq = whiten3(Rn, e, we);
     const double w = hk > 0.0 ? sqrt(huber_weight(hk, sqrt(sq))) : 1.0;
@@ -358,6 +396,18 @@ __global__ void k_error(BlockView B, const double* __restrict__ poses, const dou
     if constexpr (T == T_PTP) res_ptp(load_pose(poses + 12 * (int64_t)v[0]), points + 3 * (int64_t)v[1], B.meas + 3 * i, e, q);
     else if constexpr (T == T_STEREO) res_stereo(load_pose(poses + 12 * (int64_t)v[0]), points + 3 * (int64_t)v[1], B.meas + 3 * i, B.consts + 6 * i, e, q);
     else if constexpr (T == T_HM) res_hm(load_pose(poses + 12 * (int64_t)v[0]), load_pose(poses + 12 * (int64_t)v[1]), load_pose(B.consts + 12 * i), points + 3 * (int64_t)v[2], B.meas + 3 * i, e, q, p);
+    else if constexpr (T == T_SHM) {
+      const double* cst = B.consts + (int64_t)i * f_const(T);
+      const double zero3[3] = {0, 0, 0};
+      res_hm(load_pose(poses + 12 * (int64_t)v[0]), load_pose(poses + 12 * (int64_t)v[1]), load_pose(cst), points + 3 * (int64_t)v[2], zero3, e, q, p);
+      const double* K = cst + 12;
+      const double* z = B.meas + 3 * i;
+      if (p[2] <= 0.0) { e[0] = e[1] = e[2] = 2.0 * K[0]; }
+      else {
+        const double iz = 1.0 / p[2];
+        e[0] = K[3] + iz * K[0] * p[0] - z[0]; e[1] = K[3] + iz * K[0] * (p[0] - K[5]) - z[1]; e[2] = K[4] + iz * K[1] * p[1] - z[2];
+      }
+    }
     else if constexpr (T == T_LMP) res_lmp(points + 3 * (int64_t)v[0], points + 3 * (int64_t)v[1], load_pose(poses + 12 * (int64_t)v[2]), load_pose(poses + 12 * (int64_t)v[3]), e);
     else res_ternary(points + 3 * (int64_t)v[0], points + 3 * (int64_t)v[1], load_pose(poses + 12 * (int64_t)v[2]), e, q);
     sq = whiten3(B.noise + 9 * i, e, we);

@@ -25,6 +25,7 @@ F_LANDMARK_TERNARY = 5
 F_STEREO_POINT = 6
 F_LANDMARK_MOTION_POSE = 7
 F_LANDMARK_POSE_SMOOTHING = 8
+F_STEREO_HYBRID_MOTION = 9
 F_LINEARIZED = 16   # flag: gtsam::LinearContainerFactor of a factor of the class in the low bits
 
 F_NAMES = {
@@ -37,6 +38,7 @@ F_NAMES = {
     F_STEREO_POINT: "GenericStereoFactor",
     F_LANDMARK_MOTION_POSE: "LandmarkMotionPoseFactor",
     F_LANDMARK_POSE_SMOOTHING: "LandmarkPoseSmoothingFactor",
+    F_STEREO_HYBRID_MOTION: "StereoHybridMotionFactor",
 }
 #                 arity dim meas noise const
 F_LAYOUT = {
@@ -49,6 +51,7 @@ F_LAYOUT = {
     F_STEREO_POINT: (2, 3, 3, 9, 6),
     F_LANDMARK_MOTION_POSE: (4, 3, 0, 9, 0),
     F_LANDMARK_POSE_SMOOTHING: (3, 6, 0, 6, 0),
+    F_STEREO_HYBRID_MOTION: (3, 3, 3, 9, 18),
 }
 
 
@@ -60,7 +63,7 @@ def _lin_layout(base):
 
 SLOT_WIDTHS = {F_PRIOR_POSE3: (6,), F_BETWEEN_POSE3: (6, 6), F_POSE_TO_POINT: (6, 3), F_HYBRID_MOTION: (6, 6, 3),
                F_HYBRID_SMOOTHING: (6, 6, 6), F_LANDMARK_TERNARY: (3, 3, 6), F_STEREO_POINT: (6, 3),
-               F_LANDMARK_MOTION_POSE: (3, 3, 6, 6), F_LANDMARK_POSE_SMOOTHING: (6, 6, 6)}
+               F_LANDMARK_MOTION_POSE: (3, 3, 6, 6), F_LANDMARK_POSE_SMOOTHING: (6, 6, 6), F_STEREO_HYBRID_MOTION: (6, 6, 3)}
 for _b in list(SLOT_WIDTHS):
     F_LAYOUT[_b | F_LINEARIZED] = _lin_layout(_b)
     SLOT_WIDTHS[_b | F_LINEARIZED] = SLOT_WIDTHS[_b]

@@ -350,3 +350,42 @@ def test_wcpe_solve_and_lm_match_oracle(lib_loaded, oracle):
     assert rep.iterations == rr.iterations and rep.inner_iterations == rr.inner_iterations
     assert abs(rep.error_after - rr.error_after) <= 1e-6 * rr.error_after
     assert np.abs(c.values() - og.state()).max() <= 1e-5
+
+
+# ---- StereoHybridMotionFactor (HybridFormulationFactors.cc:213-260) ----
+def stereo_hybrid(g):
+    """the HYBRID graph with every HybridMotionFactor replaced by its stereo-projection twin"""
+    K = np.array([500.0, 500.0, 0.0, 320.0, 240.0, 0.1])
+    blocks = []
+    for b in g.blocks:
+        if b.type != G.F_HYBRID_MOTION:
+            blocks.append(b)
+            continue
+        z = b.meas                                   # camera-frame point measurement -> (uL, uR, v)
+        st = np.stack([K[3] + K[0] * z[:, 0] / z[:, 2], K[3] + K[0] * (z[:, 0] - K[5]) / z[:, 2], K[4] + K[1] * z[:, 1] / z[:, 2]], -1)
+        R = np.zeros((b.count, 9)); R[:, 0] = R[:, 4] = R[:, 8] = 1.0
+        blocks.append(G.FactorBlock(G.F_STEREO_HYBRID_MOTION, b.slot, b.var_idx, st, R, b.huber_k, np.concatenate([b.consts, np.tile(K, (b.count, 1))], 1)))
+    return G.FlatGraph(g.var_keys, g.var_type, g.var_state, blocks, dict(g.meta))
+
+
+def test_stereo_hybrid_motion_matches_oracle(lib_loaded, oracle):
+    g = stereo_hybrid(small())
+    c, og = ctx_for(g), oracle.OracleGraph(g)
+    assert abs(c.error() - og.error()) <= 1e-12 * og.error()
+    J, b, e = c.linearize()
+    Jr, br, er = og.linearize()
+    assert np.abs(J - Jr).max() <= 1e-11 * np.abs(Jr).max()
+    assert np.abs(b - br).max() <= 1e-11 * max(1.0, np.abs(br).max())
+    rep = c.optimize()
+    rr, _ = og.optimize()
+    assert rep.iterations == rr.iterations and rep.inner_iterations == rr.inner_iterations
+    assert abs(rep.error_after - rr.error_after) <= 1e-6 * rr.error_after
+    # cheirality: a point behind the camera gives the constant error 2 fx and a zero Jacobian, as the reference does
+    g2 = stereo_hybrid(small())
+    blk = [b for b in g2.blocks if b.type == G.F_STEREO_HYBRID_MOTION][0]
+    v = blk.var_idx[0, 2]
+    st = g2.var_state.copy(); st[v, :3] = -1000.0 * st[v, :3] - 500.0
+    c2, og2 = ctx_for(g2.with_state(st)), oracle.OracleGraph(g2.with_state(st))
+    J2, _, e2 = c2.linearize()
+    Jr2, _, er2 = og2.linearize()
+    assert np.abs(J2 - Jr2).max() <= 1e-11 * np.abs(Jr2).max() and np.abs(e2 - er2).max() <= 1e-9 * np.abs(er2).max()

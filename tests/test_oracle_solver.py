@@ -68,3 +68,35 @@ def test_linearize_matches_error(oracle):
     # non-robust: factor error = 0.5 * |b|^2
     assert np.allclose(0.5 * np.sum(b * b, axis=1), e, rtol=1e-12, atol=1e-300)
     assert abs(e.sum() - og.error()) <= 1e-12 * e.sum()
+
+
+def test_new_factor_classes_analytic_vs_numeric_jacobians(oracle):
+    """StereoHybridMotionFactor's analytic chain against a central difference of its own residual (the two WCPE classes
+    are numeric by definition in the reference: their columns must equal an independent central difference too)."""
+    import ctypes as C
+    rng = np.random.default_rng(2)
+    L = oracle.lib()
+
+    def pose(scale=0.3, t=1.0):
+        xi = np.concatenate([rng.normal(0, scale, 3), rng.normal(0, t, 3)])
+        return oracle.call_pose("orc_pose_expmap", xi)
+
+    def retract(p, d):
+        return oracle.call_pose("orc_pose_retract", p, d)
+
+    K = np.array([500.0, 500.0, 0.0, 320.0, 240.0, 0.1])
+    cases = [(9, [pose(), pose(0.1, 0.2), np.array([0.3, -0.2, 9.0])], np.array([300.0, 295.0, 250.0]), np.concatenate([pose(0.1, 0.3), K]), (6, 6, 3), 3),
+             (7, [rng.normal(0, 1, 3), rng.normal(0, 1, 3), pose(), pose()], None, None, (3, 3, 6, 6), 3),
+             (8, [pose(), pose(), pose()], None, None, (6, 6, 6), 6)]
+    for ftype, states, meas, consts, widths, dim in cases:
+        e, J = oracle.eval_factor(ftype, states, meas, consts)
+        for s, w in enumerate(widths):
+            for j in range(w):
+                d = np.zeros(w); d[j] = 1e-6
+                sp, sm = list(states), list(states)
+                sp[s] = retract(states[s], d) if w == 6 else states[s] + d
+                sm[s] = retract(states[s], -d) if w == 6 else states[s] - d
+                ep, _ = oracle.eval_factor(ftype, sp, meas, consts, want_J=False)
+                em, _ = oracle.eval_factor(ftype, sm, meas, consts, want_J=False)
+                num = (ep[:dim] - em[:dim]) / 2e-6
+                assert np.abs(J[:dim, 6 * s + j] - num).max() <= 2e-5 * max(1.0, np.abs(num).max()), (ftype, s, j)

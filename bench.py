@@ -135,6 +135,7 @@ def main():
             roof = dict(bound="hbm", kernel=dom["name"], achieved=dom["algorithmic_bytes"] / avg_s / 1e9,
                         peak=HBM_PEAK_GBS, unit="GB/s", traffic=None, avg_launch_us=avg_s * 1e6, launches=dom["launches"])
         roof["frac"] = roof["achieved"] / roof["peak"]
+        roof["traffic"] = pmc_traffic(roof["kernel"])
         out = {
             "metric": "LM iters/sec on 100k-factor graph", "value": value, "unit": "LM outer iterations/s (x total_factors/100k-graph factors)",
             "n_gpus": world, "steps": steps_done, "warmup": args.warmup, "ms_per_step": 1e3 * dt / max(1, steps_done),
@@ -161,6 +162,19 @@ def main():
     sys.stdout.flush()
     if rank == 0:
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/r01_pmc_hbm.txt: separate
+    FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); None if absent."""
+    try:
+        for ln in open(os.path.join(ROOT, "profiles", "r01_pmc_hbm.txt")):
+            t = ln.split()
+            if len(t) >= 5 and t[-1].endswith(kernel):
+                return (float(t[2]) + float(t[3])) * 1024.0
+    except OSError:
+        pass
+    return None
 
 
 def frontend_bench(device, cpu=True, frames=50):

@@ -12,7 +12,7 @@
 //                    diagonal targets also carry the rhs segment  r_I -= A(I,K) w_K
 //                    finalize the workgroup applying the LAST update to a diagonal tile factors it in
 //                             place and forms its inverse (look-ahead), see tall_potrf below
-//   k_back_level   backward substitution, one workgroup per target tile column of one launch
+//   k_back_group   backward substitution, BWD_GROUP levels per launch
 //
 // All arithmetic fp64.  Every reduction has a fixed order: results are run-to-run deterministic.
 #pragma once
@@ -85,6 +85,18 @@ __device__ __forceinline__ void ct_l2g(double* __restrict__ g, const double* __r
 // acc (+/-)= X Y^T for the wave's 16x16 block (bi, bj);  X[i][k] at X[i + LD k], Y[j][k] at Y[j + LD k].
 // v_mfma_f64_16x16x4_f64 operand map (cdna_hip_programming.md §3): lane l supplies A[l&15][l>>4],
 // B[l>>4][l&15]; result reg r of lane l is C[(l>>4) + 4r][l&15].
+// acc += X * Y   (Y[k][j] at Y[k + LD j])
+__device__ __forceinline__ ct_d4 ct_mma_ab(const double* __restrict__ X, const double* __restrict__ Y, int bi, int bj, int lane, ct_d4 acc) {
+  const int lr = lane >> 4, lc = lane & 15;
+  const double* xp = X + 16 * bi + lc + CT_LD * lr;
+  const double* yp = Y + lr + CT_LD * (16 * bj + lc);
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) {
+    const double a = xp[CT_LD * 4 * kk], b = yp[4 * kk];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+  }
+  return acc;
+}
 template <bool NEG>
 __device__ __forceinline__ ct_d4 ct_mma_abt(const double* __restrict__ X, const double* __restrict__ Y, int bi, int bj, int lane, ct_d4 acc) {
   const int lr = lane >> 4, lc = lane & 15;
@@ -260,18 +272,6 @@ __global__ __launch_bounds__(256) void k_chol_level(CholLevelArgs a, int task0, 
   const bool dbg_on = a.dbg && blockIdx.x == 0 && tid == 0 && (t.kind & FK_FINAL);
   CT_STAMP(0);
 
-  if (t.kind & FK_PANEL) {
-    const ct_t2 va = ct_gld(a.A + (int64_t)t.ai0 * CT_TT, tid), vl = ct_gld(a.Linv + (int64_t)t.k0 * CT_TT, tid);
-    ct_lst(XA, tid, va);
-    ct_lst(LI, tid, vl);
-    __syncthreads();
-    const ct_d4 p = ct_mma_abt<false>(XA, LI, bi, bj, lane, zero);
-    ct_store_frag(Pt, bi, bj, lane, p);
-    __syncthreads();
-    ct_l2g(a.L + (int64_t)t.tgt * CT_TT, Pt, tid);
-    return;
-  }
-
   const bool diag = (t.kind & FK_DIAG) != 0;
   double rv = 0.0;
   ct_d4 acc = zero;
@@ -389,53 +389,169 @@ __global__ __launch_bounds__(256) void k_chol_level(CholLevelArgs a, int task0, 
   CT_STAMP(6);
 }
 
-struct BackLevelArgs {
-  const BwdTask* task;
+// M(I,K) = L(I,K) Linv_K = (A(I,K) Linv_K^T) Linv_K for every off-diagonal tile of the factored columns: what the backward
+// substitution multiplies x_I with. One launch over all panels, after the factorisation (A(I,K) is final once K is).
+__global__ __launch_bounds__(256) void k_panel_m(const PanelTask* __restrict__ task, const double* __restrict__ A, const double* __restrict__ Linv,
+                                                 double* __restrict__ M) {
+  __shared__ __attribute__((aligned(16))) double XA[CT_TILE_LDS];
+  __shared__ __attribute__((aligned(16))) double LI[CT_TILE_LDS];
+  __shared__ __attribute__((aligned(16))) double Pt[CT_TILE_LDS];
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, bi = w >> 1, bj = w & 1;
+  const PanelTask t = task[blockIdx.x];
+  if (t.tile < 0) return;
+  const ct_d4 zero = {0.0, 0.0, 0.0, 0.0};
+  const ct_t2 va = ct_gld(A + (int64_t)t.tile * CT_TT, tid), vl = ct_gld(Linv + (int64_t)t.k * CT_TT, tid);
+  ct_lst(XA, tid, va);
+  ct_lst(LI, tid, vl);
+  __syncthreads();
+  const ct_d4 p = ct_mma_abt<false>(XA, LI, bi, bj, lane, zero);
+  ct_store_frag(Pt, bi, bj, lane, p);
+  __syncthreads();
+  const ct_d4 m = ct_mma_ab(Pt, LI, bi, bj, lane, zero);
+  __syncthreads();
+  ct_store_frag(XA, bi, bj, lane, m);
+  __syncthreads();
+  ct_l2g(M + (int64_t)t.tile * CT_TT, XA, tid);
+}
+
+struct BackGroupArgs {
+  const BwdCol* col;
+  const BwdPush* push;
   const BwdSrc* src;
-  const double* L;
-  const double* Linv;
-  const double* Y;
-  double* S;       // [nt*32] accumulated L(I,J)^T x_I
-  double* X;       // [nt*32] solution in elimination order
+  const double* M;     // panel tiles M(I,J) = L(I,J) Linv_J
+  const double* Wv;    // [nt*32] Linv_J^T y_J
+  double* S;           // [nt*32] accumulated M(I,J)^T x_I of the sources already pushed
+  double* X;           // [nt*32] solution in elimination order
 };
 
-__global__ __launch_bounds__(256) void k_back_level(BackLevelArgs a, int task0) {
-  __shared__ double v[CT_TS];
-  const int tid = threadIdx.x, c = tid >> 3, rg = tid & 7;
-  const BwdTask t = a.task[task0 + blockIdx.x];
-  // everything that does not depend on the sources is requested first
-  const double sprev = a.S[t.j * CT_TS + c];
-  double yv = 0.0;
-  double2 i0 = make_double2(0, 0), i1 = i0;
-  if (t.finalize) {
-    yv = a.Y[t.j * CT_TS + c];
-    const double2* ip = reinterpret_cast<const double2*>(a.Linv + (int64_t)t.j * CT_TT + 4 * rg + CT_TS * c);
-    i0 = ip[0]; i1 = ip[1];
-  }
-  double acc = 0.0;
-  BwdSrc s{t.tile0, t.i0};
-  for (int q = 0; q < t.nsrc; ++q) {
-    if (q) s = a.src[t.src0 + q];
-    const double2* lp = reinterpret_cast<const double2*>(a.L + (int64_t)s.tile * CT_TT + 4 * rg + CT_TS * c);
-    const double2* xp = reinterpret_cast<const double2*>(a.X + s.i * CT_TS + 4 * rg);
-    const double2 l0 = lp[0], l1 = lp[1], x0 = xp[0], x1 = xp[1];
-    acc += (l0.x * x0.x + l0.y * x0.y) + (l1.x * x1.x + l1.y * x1.y);
-  }
-  acc += __shfl_xor(acc, 1, 64);
-  acc += __shfl_xor(acc, 2, 64);
-  acc += __shfl_xor(acc, 4, 64);
-  const double sn = sprev + acc;
-  if (!t.finalize) {
-    if (rg == 0) a.S[t.j * CT_TS + c] = sn;
+// sum over 8 rows of one column of a tile times the matching 8 entries of x
+__device__ __forceinline__ double ct_dot8(const double2* __restrict__ m, const double2* __restrict__ x) {
+  return ((m[0].x * x[0].x + m[0].y * x[0].y) + (m[1].x * x[1].x + m[1].y * x[1].y)) +
+         ((m[2].x * x[2].x + m[2].y * x[2].y) + (m[3].x * x[3].x + m[3].y * x[3].y));
+}
+
+// One launch = BWD_GROUP levels of the backward substitution. Workgroups [0, n_group) each solve the columns of one
+// piece of the elimination tree, one 128-thread team per column: every team first gathers what does not depend on this
+// launch (w_J - s_J and the products with x of the previous launch, all loads in flight together), then the teams take
+// turns, each adding the products with the x its predecessors left in LDS. Workgroups [n_group, ...) push the x of the
+// previous launch into the accumulators of all later columns.
+constexpr int CT_BG_THREADS = 128 * BWD_MAXCOL;
+__global__ __launch_bounds__(CT_BG_THREADS) void k_back_group(BackGroupArgs a, int group0, int n_group, int push0, int n_inline, BwdInline inl) {
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x >= n_group) {
+    // ---- push: thread = (column c of the tile, 2 rows) ----
+    const BwdPush t = a.push[push0 + (int)blockIdx.x - n_group];
+    const int c = tid >> 4, rg = tid & 15;
+    double acc = 0.0;
+    for (int q0 = 0; q0 < t.nsrc; q0 += 8) {
+      double2 mv[8], xv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        mv[u] = make_double2(0.0, 0.0); xv[u] = mv[u];
+        if (q0 + u < t.nsrc) {
+          const BwdSrc sc = a.src[t.src0 + q0 + u];
+          mv[u] = *reinterpret_cast<const double2*>(a.M + (int64_t)sc.tile * CT_TT + 2 * rg + CT_TS * c);
+          xv[u] = *reinterpret_cast<const double2*>(a.X + sc.i * CT_TS + 2 * rg);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += mv[u].x * xv[u].x + mv[u].y * xv[u].y;
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    acc += __shfl_xor(acc, 8, 64);
+    if (rg == 0) a.S[t.j * CT_TS + c] += acc;
     return;
   }
-  if (rg == 0) v[c] = yv - sn;
+  __shared__ __attribute__((aligned(16))) double xl[BWD_MAXCOL][CT_TS];
+  __shared__ __attribute__((aligned(16))) double xg[BWD_MAXCOL][BWD_GLOB][CT_TS];
+  const int team = __builtin_amdgcn_readfirstlane(tid >> 7), tt = tid & 127, c = tt >> 2, rg = tt & 3;
+  // the column record: from the kernel arguments for the first groups of the launch (one dependent memory round trip less)
+  BwdCol rec;
+  if ((int)blockIdx.x < n_inline) rec = inl.c[BWD_MAXCOL * (int)blockIdx.x + team];
+  else rec = a.col[(int64_t)BWD_MAXCOL * (group0 + (int)blockIdx.x) + team];
+  const int j = rec.j;
+  double base = 0.0, acc = 0.0;
+  double2 ml[BWD_LOC][4], mg[BWD_GLOB][4];
+  if (j >= 0) {
+    // everything that does not depend on this launch, all loads in flight together
+    base = a.Wv[j * CT_TS + c] - a.S[j * CT_TS + c];
+    {
+      const int u = tt >> 4;   // 16 threads x 2 doubles per source vector
+      double2 xv = make_double2(0.0, 0.0);
+      if (u < rec.nglob) {
+        int col = 0;
+#pragma unroll
+        for (int k = 0; k < BWD_GLOB; ++k) if (k == u) col = rec.gcol[k];
+        xv = *reinterpret_cast<const double2*>(a.X + col * CT_TS + 2 * (tt & 15));
+      }
+#pragma unroll
+      for (int k = 0; k < BWD_GLOB; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mg[k][e] = make_double2(0.0, 0.0);
+#pragma unroll
+      for (int k = 0; k < BWD_GLOB; ++k)
+        if (k < rec.nglob) {
+          const double2* mp = reinterpret_cast<const double2*>(a.M + (int64_t)rec.gtile[k] * CT_TT + 8 * rg + CT_TS * c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) mg[k][e] = mp[e];
+        }
+#pragma unroll
+      for (int k = 0; k < BWD_LOC; ++k) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ml[k][e] = make_double2(0.0, 0.0);
+        if (k < rec.nloc) {
+          const double2* mp = reinterpret_cast<const double2*>(a.M + (int64_t)rec.ltile[k] * CT_TT + 8 * rg + CT_TS * c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ml[k][e] = mp[e];
+        }
+      }
+      *reinterpret_cast<double2*>(&xg[team][u][2 * (tt & 15)]) = xv;
+    }
+  }
   __syncthreads();
-  double x = (i0.x * v[4 * rg] + i0.y * v[4 * rg + 1]) + (i1.x * v[4 * rg + 2] + i1.y * v[4 * rg + 3]);
-  x += __shfl_xor(x, 1, 64);
-  x += __shfl_xor(x, 2, 64);
-  x += __shfl_xor(x, 4, 64);
-  if (rg == 0) a.X[t.j * CT_TS + c] = x;
+  if (j >= 0) {
+#pragma unroll
+    for (int k = 0; k < BWD_GLOB; ++k)
+      if (k < rec.nglob) acc += ct_dot8(mg[k], reinterpret_cast<const double2*>(&xg[team][k][8 * rg]));
+    // sources of the previous launch beyond the record (wide fronts)
+    const int ov0 = rec.src0 + (rec.nloc > BWD_LOC ? rec.nloc - BWD_LOC : 0);
+    for (int q = 0; q < rec.nglob - BWD_GLOB; ++q) {
+      const BwdSrc sc = a.src[ov0 + q];
+      const double2* mp = reinterpret_cast<const double2*>(a.M + (int64_t)sc.tile * CT_TT + 8 * rg + CT_TS * c);
+      const double2* xp = reinterpret_cast<const double2*>(a.X + sc.i * CT_TS + 8 * rg);
+      double2 mv[4], xv[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { mv[e] = mp[e]; xv[e] = xp[e]; }
+      acc += ct_dot8(mv, xv);
+    }
+  }
+  for (int step = 0; step < BWD_MAXCOL; ++step) {
+    if (team == step && j >= 0) {
+#pragma unroll
+      for (int k = 0; k < BWD_LOC; ++k)
+        if (k < rec.nloc) {
+          int sl = 0;
+#pragma unroll
+          for (int k2 = 0; k2 < BWD_LOC; ++k2) if (k2 == k) sl = rec.lslot[k2];
+          acc += ct_dot8(ml[k], reinterpret_cast<const double2*>(&xl[sl][8 * rg]));
+        }
+      for (int q = 0; q < rec.nloc - BWD_LOC; ++q) {   // more local sources than the record holds (branching pieces)
+        const BwdSrc sc = a.src[rec.src0 + q];
+        const double2* mp = reinterpret_cast<const double2*>(a.M + (int64_t)sc.tile * CT_TT + 8 * rg + CT_TS * c);
+        double2 mv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mv[e] = mp[e];
+        acc += ct_dot8(mv, reinterpret_cast<const double2*>(&xl[sc.i][8 * rg]));
+      }
+      acc += __shfl_xor(acc, 1, 64);
+      acc += __shfl_xor(acc, 2, 64);
+      const double x = base - acc;
+      if (rg == 0) { xl[team][c] = x; a.X[j * CT_TS + c] = x; }
+    }
+    __syncthreads();
+  }
 }
 
 // ---- glue between the compact pose vectors (6 per pose, every pose of the graph) and the tiled, padded layout

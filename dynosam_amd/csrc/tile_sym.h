@@ -44,17 +44,38 @@ struct FwdSrc {
   int32_t aj;     // tile id of A(I',K)  (== ai for diagonal targets and panel stores)
   int32_t k;      // source column K (index of Linv_K, w_K)
 };
-struct BwdTask {
-  int32_t j;        // target tile column
-  int32_t src0, nsrc;
-  int32_t finalize; // x_j = Linv_j^T (y_j - s_j)
-  int32_t tile0, i0;   // copy of the first source
+// Backward substitution  x_J = w_J - sum_{I in R(J)} M(I,J)^T x_I,  M(I,J) = L(I,J) Linv_J (stored by the panel tasks),
+// w_J = Linv_J^T y_J (stored when the diagonal tile is factored).  The levels are walked in reverse, BWD_GROUP levels per
+// launch: inside a launch one workgroup solves every column of one connected piece of the elimination tree (a short path
+// along a chain) one after the other, keeping their x in LDS; contributions of columns solved in EARLIER launches are
+// "pushed" into the accumulators s_J of all later columns by separate workgroups one launch after they became known.
+constexpr int BWD_GROUP = 4;      // levels per backward launch
+constexpr int BWD_MAXCOL = 4;     // columns one group workgroup solves (one 128-thread team each)
+constexpr int BWD_LOC = 3;        // sources solved earlier in the same group, held in the column record
+constexpr int BWD_GLOB = 8;       // sources solved in the previous launch, held in the column record
+struct BwdCol {
+  int32_t j;                 // tile column solved (-1: unused slot of the group)
+  int32_t nloc, nglob;       // direct sources (not yet pushed into s_j): solved earlier in this group / in the previous launch
+  int32_t src0;              // overflow list in bsrc: locals beyond BWD_LOC first, then globals beyond BWD_GLOB
+  int32_t ltile[BWD_LOC], lslot[BWD_LOC];    // tile id of M(I,J), LDS slot of x_I
+  int32_t gtile[BWD_GLOB], gcol[BWD_GLOB];   // tile id of M(I,J), tile column I (x_I read from global memory)
 };
+constexpr int BWD_INLINE_GROUPS = 2;   // groups of a launch whose column records travel as kernel arguments
+struct BwdInline { BwdCol c[BWD_INLINE_GROUPS * BWD_MAXCOL]; };
 struct BwdSrc {
-  int32_t tile;   // tile id of L(I,J)
-  int32_t i;      // source tile column I (x_I)
+  int32_t tile;
+  int32_t i;                 // tile column I, or the LDS slot for a local source of an overflow list
 };
-enum { FK_DIAG = 1, FK_FINAL = 2, FK_PANEL = 4 };
+struct BwdPush {
+  int32_t j;                 // s_j += sum_q M(tile_q)^T x_{i_q}
+  int32_t src0, nsrc;
+};
+struct BwdLaunch {
+  int32_t group0, n_group;   // group g solves the columns bcol[BWD_MAXCOL*(group0+g) ...]
+  int32_t push0, n_push;
+};
+enum { FK_DIAG = 1, FK_FINAL = 2 };
+struct PanelTask { int32_t tile, k; };   // off-diagonal tile (I,K) of an eliminated column: M(I,K) = A(I,K) Linv_K^T Linv_K
 
 struct TileSym {
   int nt = 0;
@@ -65,9 +86,11 @@ struct TileSym {
   std::vector<FwdTask> ftask;
   std::vector<FwdSrc> fsrc;
   std::vector<int32_t> flaunch;   // [n_flaunch+1] task ranges; launch 0 = leaf factorisations, launch l+1 = level l
-  std::vector<BwdTask> btask;
+  std::vector<PanelTask> panel;     // every off-diagonal tile of the eliminated columns, one launch after the factorisation
+  std::vector<BwdCol> bcol;
+  std::vector<BwdPush> bpush;
   std::vector<BwdSrc> bsrc;
-  std::vector<int32_t> blaunch;   // [n_blaunch+1]; launch q finalises level (n_levels-1-q)
+  std::vector<BwdLaunch> blaunch;   // [n_blaunch+1]; launch q finalises level (n_levels-1-q)
   double flops_factor = 0;        // fp64 flops of one numeric factorisation incl. the redundant panel re-derivations
   bool two_phase = false;         // with n_elim >= 0: ALSO schedule the remaining columns as a second phase
   std::vector<int32_t> phase_end; // index into flaunch where each phase's launches end
@@ -141,6 +164,10 @@ struct TileSym {
       build_phase(ph.first, ph.second);
       phase_end.push_back((int32_t)flaunch.size() - 1);
     }
+    panel.clear();
+    for (int K = 0; K < phases.back().second; ++K)
+      for (int32_t x = col_ptr[K] + 1; x < col_ptr[K + 1]; ++x) panel.push_back({x, K});
+    if (panel.empty()) panel.push_back({-1, 0});
   }
 
   void build_phase(int lo, int hi) {
@@ -161,13 +188,9 @@ struct TileSym {
     flaunch.push_back((int32_t)ftask.size());
     for (int l = 0; l <= maxl; ++l) {
       std::map<int32_t, std::vector<FwdSrc>> groups;   // target tile id -> sources (ordered by K: deterministic)
-      std::vector<FwdTask> panel;
-      std::vector<FwdSrc> panel_src;
       for (int K : by_level[l]) {
         const int32_t b = col_ptr[K] + 1, e = col_ptr[K + 1];
         for (int32_t x = b; x < e; ++x) {
-          panel.push_back({x, 0, 1, FK_PANEL, -1, x, x, K});
-          panel_src.push_back({x, x, K});
           for (int32_t y = b; y <= x; ++y) {
             const int32_t t = find(row_idx[x], row_idx[y]);
             groups[t].push_back({x, y, K});
@@ -194,39 +217,84 @@ struct TileSym {
         fsrc.insert(fsrc.end(), src.begin(), src.end());
         ftask.push_back(t);
       }
-      for (size_t k = 0; k < panel.size(); ++k) {
-        panel[k].src0 = (int32_t)fsrc.size();
-        fsrc.push_back(panel_src[k]);
-        ftask.push_back(panel[k]);
-        flops_factor += 2 * T3;
-      }
       flaunch.push_back((int32_t)ftask.size());
     }
   }
 
   void build_backward() {
-    btask.clear(); bsrc.clear(); blaunch.assign(1, 0);
-    // bucket[q][J] : sources I of level q+1 for target J
-    std::vector<std::map<int32_t, std::vector<BwdSrc>>> bucket(n_levels);
-    for (int J = 0; J < nt; ++J) {
-      bucket[level[J]][J];   // make sure the finalising entry exists
-      for (int32_t x = col_ptr[J] + 1; x < col_ptr[J + 1]; ++x) {
-        const int I = row_idx[x];
-        bucket[level[I] - 1][J].push_back({x, I});
+    bcol.clear(); bpush.clear(); bsrc.clear(); blaunch.clear();
+    auto root_of = [&](int J, int hi) { while (parent[J] >= 0 && level[parent[J]] <= hi) J = parent[J]; return J; };
+    // launch ranges over levels, highest first; a range shrinks until every piece fits one workgroup
+    std::vector<int> launch_of(nt, -1);
+    std::vector<std::pair<int, int>> ranges;   // [lo, hi] levels
+    for (int hi = n_levels - 1; hi >= 0;) {
+      int lo = std::max(0, hi - BWD_GROUP + 1);
+      for (; lo < hi; ++lo) {
+        std::vector<int> cnt(nt, 0);
+        bool ok = true;
+        for (int J = 0; J < nt && ok; ++J)
+          if (level[J] >= lo && level[J] <= hi && ++cnt[root_of(J, hi)] > BWD_MAXCOL) ok = false;
+        if (ok) break;
       }
+      ranges.push_back({lo, hi});
+      hi = lo - 1;
     }
-    for (int q = n_levels - 1; q >= 0; --q) {
-      // finalising targets first
-      for (int pass = 0; pass < 2; ++pass)
-        for (auto& g : bucket[q]) {
-          const bool fin = level[g.first] == q;
-          if (fin != (pass == 0)) continue;
-          btask.push_back({g.first, (int32_t)bsrc.size(), (int32_t)g.second.size(), fin ? 1 : 0,
-                           g.second.empty() ? 0 : g.second.front().tile, g.second.empty() ? 0 : g.second.front().i});
-          bsrc.insert(bsrc.end(), g.second.begin(), g.second.end());
+    for (size_t m = 0; m < ranges.size(); ++m)
+      for (int J = 0; J < nt; ++J)
+        if (level[J] >= ranges[m].first && level[J] <= ranges[m].second) launch_of[J] = (int)m;
+    std::vector<std::vector<int32_t>> by_level(n_levels);
+    for (int J = 0; J < nt; ++J) by_level[level[J]].push_back(J);
+    for (size_t m = 0; m < ranges.size(); ++m) {
+      const int lo = ranges[m].first, hi = ranges[m].second;
+      BwdLaunch bl{(int32_t)(bcol.size() / BWD_MAXCOL), 0, (int32_t)bpush.size(), 0};
+      // ---- groups: connected pieces of the tree inside [lo, hi], columns in descending level order ----
+      std::map<int, std::vector<int32_t>> piece;
+      for (int l = hi; l >= lo; --l)
+        for (int J : by_level[l]) piece[root_of(J, hi)].push_back(J);
+      for (auto& pc : piece) {
+        std::map<int32_t, int32_t> slot;
+        for (int32_t J : pc.second) {
+          std::vector<BwdSrc> loc, glob;
+          for (int32_t x = col_ptr[J] + 1; x < col_ptr[J + 1]; ++x) {
+            const int I = row_idx[x], mi = launch_of[I];
+            if (mi == (int)m) loc.push_back({x, slot.at(I)});          // an ancestor inside the range: same piece
+            else if (mi == (int)m - 1) glob.push_back({x, I});          // solved in the previous launch, not pushed yet
+          }
+          BwdCol c{};
+          c.j = J; c.nloc = (int32_t)loc.size(); c.nglob = (int32_t)glob.size(); c.src0 = (int32_t)bsrc.size();
+          for (size_t q = 0; q < loc.size(); ++q) {
+            if (q < (size_t)BWD_LOC) { c.ltile[q] = loc[q].tile; c.lslot[q] = loc[q].i; }
+            else bsrc.push_back(loc[q]);
+          }
+          for (size_t q = 0; q < glob.size(); ++q) {
+            if (q < (size_t)BWD_GLOB) { c.gtile[q] = glob[q].tile; c.gcol[q] = glob[q].i; }
+            else bsrc.push_back(glob[q]);
+          }
+          const int32_t sl = (int32_t)slot.size();
+          slot[J] = sl;
+          bcol.push_back(c);
         }
-      blaunch.push_back((int32_t)btask.size());
+        for (size_t k = pc.second.size(); k < (size_t)BWD_MAXCOL; ++k) { BwdCol c{}; c.j = -1; bcol.push_back(c); }
+        ++bl.n_group;
+      }
+      // ---- pushes: x of the previous launch into the accumulator of every column solved AFTER this launch ----
+      if (m > 0) {
+        std::map<int32_t, std::vector<BwdSrc>> push;
+        for (int J = 0; J < nt; ++J) {
+          if (launch_of[J] <= (int)m) continue;
+          for (int32_t x = col_ptr[J] + 1; x < col_ptr[J + 1]; ++x)
+            if (launch_of[row_idx[x]] == (int)m - 1) push[J].push_back({x, row_idx[x]});
+        }
+        for (auto& g : push) {
+          bpush.push_back({g.first, (int32_t)bsrc.size(), (int32_t)g.second.size()});
+          bsrc.insert(bsrc.end(), g.second.begin(), g.second.end());
+          ++bl.n_push;
+        }
+      }
+      blaunch.push_back(bl);
     }
+    if (bsrc.empty()) bsrc.push_back({0, 0});
+    if (bpush.empty()) bpush.push_back({0, 0, 0});
   }
 };
 

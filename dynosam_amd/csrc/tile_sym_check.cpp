@@ -102,11 +102,7 @@ int main(int argc, char** argv) {
     std::shuffle(ids.begin(), ids.end(), rng);
     for (int32_t id : ids) {
       const FwdTask& t = sym.ftask[id];
-      if (t.kind & FK_PANEL) {
-        const FwdSrc& sc = sym.fsrc[t.src0];
-        mul_abt(&A[(size_t)sc.ai * TT], &Li[(size_t)sc.k * TT], &L[(size_t)t.tgt * TT]);
-        continue;
-      }
+
       double* T = &A[(size_t)t.tgt * TT];
       for (int32_t q = t.src0; q < t.src0 + t.nsrc; ++q) {
         const FwdSrc& sc = sym.fsrc[q];
@@ -135,23 +131,58 @@ int main(int argc, char** argv) {
       }
     }
   }
-  // ---- backward ----
-  for (size_t q = 0; q + 1 < sym.blaunch.size(); ++q) {
-    std::vector<int32_t> ids;
-    for (int32_t t = sym.blaunch[q]; t < sym.blaunch[q + 1]; ++t) ids.push_back(t);
-    std::shuffle(ids.begin(), ids.end(), rng);
-    for (int32_t id : ids) {
-      const BwdTask& t = sym.btask[id];
-      for (int32_t k = t.src0; k < t.src0 + t.nsrc; ++k) {
-        const BwdSrc& sc = sym.bsrc[k];
-        const double* Lt = &L[(size_t)sc.tile * TT];
-        for (int c = 0; c < TS; ++c) { double acc = 0; for (int rr = 0; rr < TS; ++rr) acc += Lt[rr + TS * c] * x[sc.i * TS + rr]; s[t.j * TS + c] += acc; }
+  // ---- panels: M(I,K) = (A Linv^T) Linv ----
+  for (const PanelTask& pt : sym.panel) {
+    if (pt.tile < 0) continue;
+    mul_abt(&A[(size_t)pt.tile * TT], &Li[(size_t)pt.k * TT], P.data());
+    const double* li = &Li[(size_t)pt.k * TT];
+    double* M = &L[(size_t)pt.tile * TT];
+    for (int i = 0; i < TS; ++i)
+      for (int j = 0; j < TS; ++j) {
+        double acc = 0;
+        for (int k = 0; k < TS; ++k) acc += P[i + TS * k] * li[k + TS * j];
+        M[i + TS * j] = acc;
       }
-      if (t.finalize) {
-        const double* li = &Li[(size_t)t.j * TT];
-        for (int c = 0; c < TS; ++c) { double acc = 0; for (int rr = c; rr < TS; ++rr) acc += li[rr + TS * c] * (y[t.j * TS + rr] - s[t.j * TS + rr]); x[t.j * TS + c] = acc; }
+  }
+  // ---- backward: x_J = w_J - s_J - sum M^T x ----
+  auto mtx = [&](int tile, const double* xs, double* out, double sgn) {
+    const double* Mt = &L[(size_t)tile * TT];
+    for (int c = 0; c < TS; ++c) { double acc = 0; for (int rr = 0; rr < TS; ++rr) acc += Mt[rr + TS * c] * xs[rr]; out[c] += sgn * acc; }
+  };
+  for (const BwdLaunch& bl : sym.blaunch) {
+    std::vector<int32_t> ids;
+    for (int32_t t = 0; t < bl.n_group + bl.n_push; ++t) ids.push_back(t);
+    std::shuffle(ids.begin(), ids.end(), rng);
+    std::vector<double> xnew(npad, 0.0);
+    std::vector<char> solved(nt, 0);
+    for (int32_t id : ids) {
+      if (id >= bl.n_group) {
+        const BwdPush& t = sym.bpush[bl.push0 + id - bl.n_group];
+        for (int32_t k = t.src0; k < t.src0 + t.nsrc; ++k) mtx(sym.bsrc[k].tile, &x[sym.bsrc[k].i * TS], &s[t.j * TS], 1.0);
+        continue;
+      }
+      std::vector<std::vector<double>> xl;
+      for (int k = 0; k < BWD_MAXCOL; ++k) {
+        const BwdCol& col = sym.bcol[(size_t)BWD_MAXCOL * (bl.group0 + id) + k];
+        if (col.j < 0) break;
+        std::vector<double> v(TS);
+        for (int c = 0; c < TS; ++c) v[c] = w[col.j * TS + c] - s[col.j * TS + c];
+        int32_t ov = col.src0;
+        for (int32_t q = 0; q < col.nloc; ++q) {
+          if (q < BWD_LOC) mtx(col.ltile[q], xl[col.lslot[q]].data(), v.data(), -1.0);
+          else { mtx(sym.bsrc[ov].tile, xl[sym.bsrc[ov].i].data(), v.data(), -1.0); ++ov; }
+        }
+        for (int32_t q = 0; q < col.nglob; ++q) {
+          if (q < BWD_GLOB) mtx(col.gtile[q], &x[col.gcol[q] * TS], v.data(), -1.0);
+          else { mtx(sym.bsrc[ov].tile, &x[sym.bsrc[ov].i * TS], v.data(), -1.0); ++ov; }
+        }
+        xl.push_back(v);
+        for (int c = 0; c < TS; ++c) xnew[col.j * TS + c] = v[c];
+        solved[col.j] = 1;
       }
     }
+    // x of this launch becomes visible to the next one only (tasks of one launch never read it from global memory)
+    for (int J = 0; J < nt; ++J) if (solved[J]) for (int c = 0; c < TS; ++c) x[J * TS + c] = xnew[J * TS + c];
   }
   // ---- dense reference: residual of S x = g ----
   double rmax = 0, gmax = 0;
@@ -161,7 +192,7 @@ int main(int argc, char** argv) {
     rmax = std::max(rmax, std::fabs(acc - g[i]));
     gmax = std::max(gmax, std::fabs(g[i]));
   }
-  printf("phases=%zu nt=%d tiles=%lld levels=%d fwd_launches=%zu fwd_tasks=%zu bwd_tasks=%zu residual=%.3e %s\n", sym.phase_end.size(), nt, (long long)sym.n_tiles, sym.n_levels,
-         sym.flaunch.size() - 1, sym.ftask.size(), sym.btask.size(), rmax / gmax, (rmax / gmax < 1e-10) ? "OK" : "FAIL");
+  printf("phases=%zu nt=%d tiles=%lld levels=%d fwd_launches=%zu fwd_tasks=%zu bwd_launches=%zu residual=%.3e %s\n", sym.phase_end.size(), nt, (long long)sym.n_tiles, sym.n_levels,
+         sym.flaunch.size() - 1, sym.ftask.size(), sym.blaunch.size(), rmax / gmax, (rmax / gmax < 1e-10) ? "OK" : "FAIL");
   return (rmax / gmax < 1e-10) ? 0 : 1;
 }

@@ -258,7 +258,24 @@ struct CholLevelArgs {
 constexpr int CT_NB = CT_NB_VALUE;   // columns per panel step of the diagonal-tile factorisation
 #define CT_STAMP(k) do { if (dbg_on) a.dbg[16 * lvl + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
 
-__global__ __launch_bounds__(256) void k_chol_level(CholLevelArgs a, int task0, int lvl) {
+// read a POD from the kernel-argument segment at a wave-uniform byte offset (scalar loads)
+template <typename T>
+__device__ __forceinline__ T ct_kernarg_load(size_t byte_off) {
+  static_assert(sizeof(T) % 4 == 0, "dword records");
+  typedef __attribute__((address_space(4))) const uint32_t* kptr_t;
+  kptr_t p = (kptr_t)((__attribute__((address_space(4))) const char*)__builtin_amdgcn_kernarg_segment_ptr() + byte_off);
+  union { T v; uint32_t w[sizeof(T) / 4]; } u;
+#pragma unroll
+  for (size_t k = 0; k < sizeof(T) / 4; ++k) u.w[k] = p[k];
+  // pin the loads here (next to the loads of the arguments themselves) instead of wherever the value is first needed
+#pragma unroll
+  for (size_t k = 0; k < sizeof(T) / 4; ++k) asm volatile("" : "+s"(u.w[k]));
+  return u.v;
+}
+constexpr int CT_FWD_INLINE = 4;   // task records of the first (finalising = critical) workgroups travel as kernel arguments
+struct FwdInline { FwdTask t[CT_FWD_INLINE]; };
+struct CholLevelKernarg { CholLevelArgs a; int task0, lvl, n_inline; FwdInline inl; };   // layout of k_chol_level's arguments
+__global__ __launch_bounds__(256) void k_chol_level(CholLevelArgs a, int task0, int lvl, int n_inline, FwdInline inl) {
   __shared__ __attribute__((aligned(16))) double XA[CT_TILE_LDS];
   __shared__ __attribute__((aligned(16))) double XB[CT_TILE_LDS];
   __shared__ __attribute__((aligned(16))) double LI[CT_TILE_LDS];
@@ -267,7 +284,11 @@ __global__ __launch_bounds__(256) void k_chol_level(CholLevelArgs a, int task0, 
   __shared__ double part[8][CT_TS + 1];
   __shared__ double wk[CT_TS], yv[CT_TS], rvs[CT_TS];
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, bi = w >> 1, bj = w & 1;
-  const FwdTask t = a.task[task0 + blockIdx.x];
+  // the record of a finalising (critical) workgroup is read from the kernel-argument segment with scalar loads issued
+  // together with the arguments themselves: one dependent memory round trip less on the critical path
+  FwdTask t = ct_kernarg_load<FwdTask>(offsetof(CholLevelKernarg, inl) + sizeof(FwdTask) * min((int)blockIdx.x, CT_FWD_INLINE - 1));
+  if ((int)blockIdx.x >= n_inline) t = a.task[task0 + blockIdx.x];
+  (void)inl;
   const ct_d4 zero = {0.0, 0.0, 0.0, 0.0};
   const bool dbg_on = a.dbg && blockIdx.x == 0 && tid == 0 && (t.kind & FK_FINAL);
   CT_STAMP(0);
@@ -436,6 +457,7 @@ __device__ __forceinline__ double ct_dot8(const double2* __restrict__ m, const d
 // turns, each adding the products with the x its predecessors left in LDS. Workgroups [n_group, ...) push the x of the
 // previous launch into the accumulators of all later columns.
 constexpr int CT_BG_THREADS = 128 * BWD_MAXCOL;
+struct BackGroupKernarg { BackGroupArgs a; int group0, n_group, push0, n_inline; BwdInline inl; };   // layout of k_back_group's arguments
 __global__ __launch_bounds__(CT_BG_THREADS) void k_back_group(BackGroupArgs a, int group0, int n_group, int push0, int n_inline, BwdInline inl) {
   const int tid = threadIdx.x;
   if ((int)blockIdx.x >= n_group) {
@@ -468,9 +490,10 @@ __global__ __launch_bounds__(CT_BG_THREADS) void k_back_group(BackGroupArgs a, i
   __shared__ __attribute__((aligned(16))) double xg[BWD_MAXCOL][BWD_GLOB][CT_TS];
   const int team = __builtin_amdgcn_readfirstlane(tid >> 7), tt = tid & 127, c = tt >> 2, rg = tt & 3;
   // the column record: from the kernel arguments for the first groups of the launch (one dependent memory round trip less)
-  BwdCol rec;
-  if ((int)blockIdx.x < n_inline) rec = inl.c[BWD_MAXCOL * (int)blockIdx.x + team];
-  else rec = a.col[(int64_t)BWD_MAXCOL * (group0 + (int)blockIdx.x) + team];
+  BwdCol rec = ct_kernarg_load<BwdCol>(offsetof(BackGroupKernarg, inl) +
+                                       sizeof(BwdCol) * (BWD_MAXCOL * min((int)blockIdx.x, BWD_INLINE_GROUPS - 1) + team));
+  if ((int)blockIdx.x >= n_inline) rec = a.col[(int64_t)BWD_MAXCOL * (group0 + (int)blockIdx.x) + team];
+  (void)inl;
   const int j = rec.j;
   double base = 0.0, acc = 0.0;
   double2 ml[BWD_LOC][4], mg[BWD_GLOB][4];

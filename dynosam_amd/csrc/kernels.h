@@ -653,7 +653,8 @@ struct ChainEdgeView {
 };
 
 __global__ void k_chain_edge(ChainEdgeView E, const int32_t* __restrict__ ch_point, const double* const* __restrict__ Jpp,
-                             const double* __restrict__ Cq, const double* __restrict__ Bq, double* __restrict__ Z) {
+                             const double* __restrict__ Cq, const double* __restrict__ Bq, const int32_t* __restrict__ e_zpos,
+                             double* __restrict__ Z, double* __restrict__ Zp) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E.n_cedge) return;
   const double* __restrict__ Jbuf = *Jpp;
@@ -693,11 +694,13 @@ __global__ void k_chain_edge(ChainEdgeView E, const int32_t* __restrict__ ch_poi
       Yp[6 + j] = C[1] * w0 + C[3] * w1;
       Yp[12 + j] = C[2] * w0 + C[4] * w1 + C[5] * w2;
     }
-    double* z = Z + 18 * (int64_t)E.ce_subid[E.ce_sptr[e] + (pos - E.ce_first[e])];
+    const int32_t sub = E.ce_subid[E.ce_sptr[e] + (pos - E.ce_first[e])];
+    double* z = Z + 18 * (int64_t)sub;
+    double* zp = Zp + 18 * (int64_t)e_zpos[sub];
 #pragma unroll
     for (int i = 0; i < 6; ++i)
 #pragma unroll
-      for (int c = 0; c < 3; ++c) z[i * 3 + c] = Yp[c * 6 + i];
+      for (int c = 0; c < 3; ++c) { z[i * 3 + c] = Yp[c * 6 + i]; zp[i * 3 + c] = Yp[c * 6 + i]; }
   }
 }
 
@@ -731,9 +734,13 @@ struct EdgeView {
   const int32_t* e_point;
   const int64_t* e_jc;     // offset of Jc (3x6 row-major)
   const int64_t* e_jp;     // offset of Jp (3x3)
+  const int32_t* e_zpos;   // row of the edge in the pose-major copy of Z
 };
 
-__global__ void k_edge_z(EdgeView E, const double* const* __restrict__ Jpp, const double* __restrict__ Cq, double* __restrict__ Z) {
+// Z is kept twice: rows in edge order (edges of a point contiguous: back-substitution of the points) and in pose-major
+// order (edges of a pose contiguous: the Schur assembly and the reduced rhs walk them almost sequentially).
+__global__ void k_edge_z(EdgeView E, const double* const* __restrict__ Jpp, const double* __restrict__ Cq, double* __restrict__ Z,
+                         double* __restrict__ Zp) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E.n_edge || E.e_jc[e] < 0) return;   // e_jc < 0: sub-edge of a point chain, written by k_chain_edge
   const double* __restrict__ Jbuf = *Jpp;
@@ -748,10 +755,14 @@ __global__ void k_edge_z(EdgeView E, const double* const* __restrict__ Jpp, cons
     M[r * 3 + 2] = Jp[r * 3] * C[2] + Jp[r * 3 + 1] * C[4] + Jp[r * 3 + 2] * C[5];
   }
   double* z = Z + 18 * e;
+  double* zp = Zp + 18 * (int64_t)E.e_zpos[e];
 #pragma unroll
   for (int i = 0; i < 6; ++i)
 #pragma unroll
-    for (int k = 0; k < 3; ++k) z[i * 3 + k] = Jc[i] * M[k] + Jc[6 + i] * M[3 + k] + Jc[12 + i] * M[6 + k];
+    for (int k = 0; k < 3; ++k) {
+      const double v = Jc[i] * M[k] + Jc[6 + i] * M[3 + k] + Jc[12 + i] * M[6 + k];
+      z[i * 3 + k] = v; zp[i * 3 + k] = v;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -769,7 +780,7 @@ struct AssembleView {
   const int32_t* ch_kind;  // 0: schur pairs, 1: direct
   const int32_t* ch_lo;    // first contribution of the chunk (index into sp_e pairs / dp_* arrays)
   const int32_t* ch_n;     // <= 64
-  const int32_t* sp_e;     // [2*npairs] edge ids
+  const int32_t* sp_e;     // [2*npairs] rows of the pose-major Z
   const int64_t* dp_a;     // offset of A_a (d x 6)
   const int64_t* dp_b;
   const int8_t* dp_d;
@@ -782,55 +793,76 @@ struct AssembleView {
   int prior_dim;
 };
 
-// pass 1: one wavefront per chunk of <= 64 contributions to ONE 6x6 block. Lanes first fetch the
-// chunk's indices (one contribution per lane, coalesced), then lanes 0..35 = (i,j) walk the chunk
-// with the indices broadcast by readlane, so the Z / J loads of successive contributions are
-// independent and pipeline.  Fixed order => deterministic.
+// pass 1: one wavefront per chunk of <= 64 contributions to ONE 6x6 block. Lanes first fetch the chunk's indices (one
+// contribution per lane, coalesced); the chunk is then walked with the indices broadcast by readlane, one fp64 MFMA
+// (16x16x4) per contribution: the K slots 0..2 carry the 3 columns of the two 6x3 Z rows (slot 3 is zero), the 6x6
+// product sits in the top-left corner of the 16x16 accumulator. Each lane loads ONE double per operand - the vector
+// memory pipeline, not arithmetic, bounds this kernel, and the scalar formulation issued 6 loads per contribution.
+// Fixed order => deterministic.
 __global__ __launch_bounds__(256) void k_assemble_chunks(AssembleView A, const double* const* __restrict__ Jpp,
                                                          const double* __restrict__ Z, double* __restrict__ partial) {
+  typedef double d4_t __attribute__((ext_vector_type(4)));
   const double* __restrict__ Jbuf = *Jpp;
-  const int64_t ch = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  // chunks are sorted by block (row pose, column pose): workgroup ids round-robin over the 8 XCDs, so give every XCD one
+  // contiguous eighth of the chunk list - its L2 then holds the Z rows of "its" poses (grid = 8 * per)
+  const int64_t per = gridDim.x >> 3;
+  const int64_t wg = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  const int64_t ch = wg * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (ch >= A.n_chunk) return;
   const int n = A.ch_n[ch], lo = A.ch_lo[ch];
-  const int i = (lane < 36) ? lane / 6 : 0, j = (lane < 36) ? lane % 6 : 0;
-  double acc = 0;
+  const int ij = lane & 15, g = lane >> 4;       // operand row (A: i, B: j) and K slot
+  const bool act = ij < 6;
+  d4_t acc = {0.0, 0.0, 0.0, 0.0};
   if (A.ch_kind[ch] == 0) {
     int e1 = 0, e2 = 0;
     if (lane < n) { e1 = A.sp_e[2 * (lo + lane)]; e2 = A.sp_e[2 * (lo + lane) + 1]; }
-    // 4 contributions per trip: their 24 loads are independent and issue back to back
+    const bool ld = act && g < 3;
+    const int zo = ld ? 3 * ij + g : 0;
+    // 4 contributions per trip: their loads are independent and issue back to back
     for (int k0 = 0; k0 < n; k0 += 4) {
-      double t[4];
+      double a[4], b[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int k = k0 + u;   // lanes >= n hold edge 0 (a valid address); masked by w
+        const int k = k0 + u;   // lanes >= n hold row 0 (a valid address); masked below
         const int f1 = __builtin_amdgcn_readlane(e1, k & 63), f2 = __builtin_amdgcn_readlane(e2, k & 63);
-        const double* z1 = Z + 18 * (int64_t)f1 + 3 * i;
-        const double* z2 = Z + 18 * (int64_t)f2 + 3 * j;
-        t[u] = (k < n) ? z1[0] * z2[0] + z1[1] * z2[1] + z1[2] * z2[2] : 0.0;
+        a[u] = 0.0; b[u] = 0.0;
+        if (ld && k < n) { a[u] = -Z[18 * (int64_t)f1 + zo]; b[u] = Z[18 * (int64_t)f2 + zo]; }
       }
-      acc -= (t[0] + t[1]) + (t[2] + t[3]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
     }
   } else {
     int64_t oa = 0, ob = 0;
     int d = 0;
     if (lane < n) { oa = A.dp_a[lo + lane]; ob = A.dp_b[lo + lane]; d = A.dp_d[lo + lane]; }
+    double pacc0 = 0.0, pacc1 = 0.0;   // constant blocks of the dense prior, in the accumulator's layout
 #pragma unroll 2
     for (int k = 0; k < n; ++k) {
       const int64_t pa = ((int64_t)__builtin_amdgcn_readlane((int)(oa >> 32), k) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)oa, k);
       const int64_t pb = ((int64_t)__builtin_amdgcn_readlane((int)(ob >> 32), k) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)ob, k);
       const int dd = __builtin_amdgcn_readlane(d, k);
-      if (dd < 0) {   // constant block of the dense prior: rows pa.., columns pb.. of Lambda
-        acc += A.prior_L[(pa + i) * A.prior_dim + pb + j];
+      if (dd < 0) {   // rows pa.., columns pb.. of Lambda
+        if (act) {
+          pacc0 += A.prior_L[(pa + g) * A.prior_dim + pb + ij];
+          if (g < 2) pacc1 += A.prior_L[(pa + 4 + g) * A.prior_dim + pb + ij];
+        }
         continue;
       }
-      const double* Aa = Jbuf + pa + i;
-      const double* Ab = Jbuf + pb + j;
-      acc += Aa[0] * Ab[0] + Aa[6] * Ab[6] + Aa[12] * Ab[12];
-      if (dd == 6) acc += Aa[18] * Ab[18] + Aa[24] * Ab[24] + Aa[30] * Ab[30];
+      // rows g and 4+g of the two d x 6 Jacobian blocks
+      double a0 = 0.0, b0 = 0.0, a1 = 0.0, b1 = 0.0;
+      if (act && g < dd) { a0 = Jbuf[pa + 6 * g + ij]; b0 = Jbuf[pb + 6 * g + ij]; }
+      if (act && 4 + g < dd) { a1 = Jbuf[pa + 6 * (4 + g) + ij]; b1 = Jbuf[pb + 6 * (4 + g) + ij]; }
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
+      if (dd > 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 0);
     }
+    acc[0] += pacc0; acc[1] += pacc1;
   }
-  if (lane < 36) partial[ch * 36 + lane] = acc;
+  // accumulator: lane (j = lane & 15, g = lane >> 4) holds rows g + 4 r, r = 0..3, of column j
+  if (act) {
+    partial[ch * 36 + 6 * g + ij] = acc[0];
+    if (g < 2) partial[ch * 36 + 6 * (4 + g) + ij] = acc[1];
+  }
 }
 
 // pass 2: one lane per (block, element): sum the block's chunk partials in order, add damping, store
@@ -900,7 +932,7 @@ __global__ __launch_bounds__(256) void k_rhs(RhsView R, const double* const* __r
   }
   for (int k = R.pe_ptr[a] + lane; k < R.pe_ptr[a + 1]; k += 64) {
     const int e = R.pe_edge[k];
-    const double* z = Z + 18 * (int64_t)e;
+    const double* z = Z + 18 * (int64_t)k;   // pose-major copy: row k belongs to edge pe_edge[k]
     const double* u = uq + 3 * (int64_t)R.e_point[e];
 #pragma unroll
     for (int c = 0; c < 6; ++c) g[c] -= z[c * 3] * u[0] + z[c * 3 + 1] * u[1] + z[c * 3 + 2] * u[2];

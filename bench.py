@@ -214,6 +214,19 @@ def frontend_bench(device, cpu=True, frames=50):
                         "frac": corr_tflops / 2500.0, "traffic": None,
                         "note": "bf16 32x32x16 MFMA flops issued (windowed all-pairs volume at 1/8 resolution) / HIP-event time"},
            "data": "synthetic textured scene, exact flow (dynosam_amd/synth_images.py)"}
+    # static-feature path: 800 background points through the sparse pyramidal LK (forward + reverse + flow-back check),
+    # = KltFeatureTracker::trackPoints' optical-flow part; wall time per call incl. the point upload / result download
+    ysb, xsb = np.nonzero((sc["mask0"] == 0) & sc["valid"])
+    pb = rng.choice(len(xsb), 800, replace=False)
+    spts = np.stack([xsb[pb], ysb[pb]], -1).astype(np.float32)
+    k0 = t.track_points_klt(spts)
+    t1 = time.perf_counter()
+    for _ in range(20):
+        k0 = t.track_points_klt(spts)
+    kdt = (time.perf_counter() - t1) / 20
+    kerr = np.linalg.norm(k0["cur"] - spts - sc["flow_gt"][ysb[pb], xsb[pb]], axis=1)[k0["status"] == 1]
+    out["static_klt"] = {"points": 800, "ms_per_call": 1e3 * kdt, "tracked": int(k0["status"].sum()), "err_median_px": float(np.median(kerr)),
+                         "note": "21x21 window, 4 levels forward / 5 reverse, 30 iterations max; bit-exact against oracle/klt_oracle.py"}
     if cpu:
         from oracle import flow_oracle as FO
         c0 = time.perf_counter()

@@ -1,0 +1,54 @@
+"""CPU checks of the Shi-Tomasi oracle (oracle/gftt_oracle.py): response properties, mask / min-distance / ordering rules of
+cv::goodFeaturesToTrack as restated there.  Parity with the OpenCV binary is unpinned (see the oracle's header)."""
+import numpy as np
+
+from oracle import gftt_oracle as G
+
+
+def _checker(h=96, w=128, cell=16):
+    ys, xs = np.mgrid[0:h, 0:w]
+    return (((ys // cell) + (xs // cell)) % 2 * 200 + 20).astype(np.uint8)
+
+
+def test_response_is_zero_on_flat_and_edge_regions_and_peaks_at_corners():
+    img = _checker()
+    eig = G.min_eigen_val(img)
+    assert eig.dtype == np.float32 and eig.shape == img.shape
+    assert eig[8, 8] == 0.0                                  # flat
+    assert abs(eig[8, 16]) < 1e-9 and abs(eig[16, 8]) < 1e-9   # pure edges: rank-1 structure tensor
+    assert eig[16, 16] > 1e-3 and eig[15:18, 15:18].max() == eig.max()   # checker corner
+
+
+def test_corners_sit_on_the_checker_lattice_sorted_and_separated():
+    img = _checker()
+    c, eig = G.good_features_to_track(img, None, max_corners=100, quality_level=0.01, min_distance=8.0)
+    assert len(c) == 5 * 7                                   # interior lattice crossings
+    assert np.all(np.abs((c + 0.5) / 16 - np.round((c + 0.5) / 16)) <= 1.0 / 16)
+    v = eig[c[:, 1].astype(int), c[:, 0].astype(int)]
+    assert np.all(np.diff(v) <= 0)                           # strongest first
+    d = np.linalg.norm(c[:, None] - c[None], axis=-1) + 1e9 * np.eye(len(c))
+    assert d.min() >= 8.0
+
+
+def test_mask_limits_max_and_candidates_and_max_corners_truncates():
+    img = _checker()
+    mask = np.zeros(img.shape, np.uint8)
+    mask[:, :64] = 255
+    c, _ = G.good_features_to_track(img, mask, max_corners=100, quality_level=0.01, min_distance=8.0)
+    assert len(c) > 0 and np.all(c[:, 0] < 64)
+    c3, _ = G.good_features_to_track(img, mask, max_corners=3, quality_level=0.01, min_distance=8.0)
+    assert np.array_equal(c3, c[:3])
+    assert len(G.good_features_to_track(img, np.zeros(img.shape, np.uint8))[0]) == 0
+    flat = np.full((64, 64), 50, np.uint8)
+    assert len(G.good_features_to_track(flat)[0]) == 0
+
+
+def test_ties_prefer_the_higher_address():
+    # two identical isolated blobs: equal responses; greaterThanPtr puts the higher address first
+    img = np.full((64, 96), 30, np.uint8)
+    img[20:24, 20:24] = 220
+    img[20:24, 60:64] = 220
+    c, eig = G.good_features_to_track(img, None, max_corners=2, quality_level=0.5, min_distance=1.0)
+    assert len(c) == 2
+    i0, i1 = c[0, 1] * 96 + c[0, 0], c[1, 1] * 96 + c[1, 0]
+    assert eig[int(c[0, 1]), int(c[0, 0])] == eig[int(c[1, 1]), int(c[1, 0])] and i0 > i1

@@ -39,6 +39,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-frontend", action="store_true", help="skip the frontend (dense flow + feature propagation) leg")
     ap.add_argument("--force-collective", action="store_true", help="use the RCCL all-reduce path even with one rank (plumbing check)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: validation only - ranks may share one GPU, the all-reduce is staged through the host")
+    ap.add_argument("--scale", type=int, default=0, help="trajectory multiplier of the weak-scaling graph (default: world size)")
     args = ap.parse_args()
 
     import numpy as np
@@ -50,6 +53,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.backend == "gloo":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     collective = world > 1 or args.force_collective
     # RCCL writes banners / warnings to the C-level stdout: park fd 1 on stderr for the run and keep the real stdout
@@ -60,18 +65,22 @@ def main():
     if collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from dynosam_amd import synth
     from dynosam_amd.optimizer import Context, LevenbergMarquardtParams
 
     cfg = synth.config(args.config)
     base_factors = None
-    if world > 1:  # weak scaling: N x longer trajectory, same per-frame density
+    mult = args.scale or world
+    if mult > 1:  # weak scaling: N x longer trajectory, same per-frame density
         g1 = synth.make_hybrid_graph(cfg)
         base_factors = g1.n_factors
-        cfg = synth.config(args.config, frames=cfg.frames * world, static_points=cfg.static_points * world,
-                           dynamic_points_per_object=cfg.dynamic_points_per_object * world)
+        cfg = synth.config(args.config, frames=cfg.frames * mult, static_points=cfg.static_points * mult,
+                           dynamic_points_per_object=cfg.dynamic_points_per_object * mult)
     g = synth.make_hybrid_graph(cfg)
     if base_factors is None:
         base_factors = g.n_factors
@@ -85,7 +94,12 @@ def main():
         storage = torch._C._construct_storage_from_data_pointer(ptr, torch.device("cuda", local_rank), count * 8)
         buf.set_(storage, 0, (count,))
         with torch.cuda.stream(stream):
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+            if args.backend == "nccl":
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+            else:
+                host = buf.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM)
+                buf.copy_(host)
         stream.synchronize()
 
     ctx = Context(device=local_rank, world_size=world, rank=rank, allreduce=allreduce if collective else None,
@@ -113,7 +127,7 @@ def main():
     rep = run(args.steps)
     sync()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
     if collective:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())

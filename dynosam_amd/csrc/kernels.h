@@ -1272,6 +1272,14 @@ __global__ void k_backsub_points(PointEdgeView V, const double* __restrict__ Z, 
   dpoint[3 * q + 2] = C[5] * s2;
 }
 
+// sharded path: the part of the replicated state this rank is the source of (zero elsewhere); SUM over ranks = full state
+__global__ void k_mask_values(const double* __restrict__ poses, const double* __restrict__ points, const uint8_t* __restrict__ mine_pose,
+                              const uint8_t* __restrict__ mine_point, int64_t n_pose, int64_t n_point, double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 12 * n_pose) out[i] = mine_pose[i / 12] ? poses[i] : 0.0;
+  else if (i < 12 * n_pose + 3 * n_point) { const int64_t j = i - 12 * n_pose; out[i] = mine_point[j / 3] ? points[j] : 0.0; }
+}
+
 __global__ void k_retract(const double* __restrict__ poses, const double* __restrict__ points, const double* __restrict__ dpose,
                           const double* __restrict__ dpoint, int64_t n_pose, int64_t n_point, double* __restrict__ poses_out,
                           double* __restrict__ points_out) {

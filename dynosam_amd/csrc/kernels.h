@@ -784,6 +784,7 @@ struct AssembleView {
   const int64_t* dp_a;     // offset of A_a (d x 6)
   const int64_t* dp_b;
   const int8_t* dp_d;
+  const uint8_t* dp_w;     // column counts of the two blocks: wa | wb << 4 (6: pose, 3: a point kept in the reduced system)
   int64_t n_blk;
   const int32_t* blk_a;
   const int32_t* blk_b;
@@ -834,14 +835,15 @@ __global__ __launch_bounds__(256) void k_assemble_chunks(AssembleView A, const d
     }
   } else {
     int64_t oa = 0, ob = 0;
-    int d = 0;
-    if (lane < n) { oa = A.dp_a[lo + lane]; ob = A.dp_b[lo + lane]; d = A.dp_d[lo + lane]; }
+    int d = 0, wv = 0x66;
+    if (lane < n) { oa = A.dp_a[lo + lane]; ob = A.dp_b[lo + lane]; d = A.dp_d[lo + lane]; wv = A.dp_w[lo + lane]; }
     double pacc0 = 0.0, pacc1 = 0.0;   // constant blocks of the dense prior, in the accumulator's layout
 #pragma unroll 2
     for (int k = 0; k < n; ++k) {
       const int64_t pa = ((int64_t)__builtin_amdgcn_readlane((int)(oa >> 32), k) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)oa, k);
       const int64_t pb = ((int64_t)__builtin_amdgcn_readlane((int)(ob >> 32), k) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)ob, k);
       const int dd = __builtin_amdgcn_readlane(d, k);
+      const int ww = __builtin_amdgcn_readlane(wv, k), wa = ww & 15, wb = ww >> 4;
       if (dd < 0) {   // rows pa.., columns pb.. of Lambda
         if (act) {
           pacc0 += A.prior_L[(pa + g) * A.prior_dim + pb + ij];
@@ -851,8 +853,8 @@ __global__ __launch_bounds__(256) void k_assemble_chunks(AssembleView A, const d
       }
       // rows g and 4+g of the two d x 6 Jacobian blocks
       double a0 = 0.0, b0 = 0.0, a1 = 0.0, b1 = 0.0;
-      if (act && g < dd) { a0 = Jbuf[pa + 6 * g + ij]; b0 = Jbuf[pb + 6 * g + ij]; }
-      if (act && 4 + g < dd) { a1 = Jbuf[pa + 6 * (4 + g) + ij]; b1 = Jbuf[pb + 6 * (4 + g) + ij]; }
+      if (act && g < dd) { if (ij < wa) a0 = Jbuf[pa + wa * g + ij]; if (ij < wb) b0 = Jbuf[pb + wb * g + ij]; }
+      if (act && 4 + g < dd) { if (ij < wa) a1 = Jbuf[pa + wa * (4 + g) + ij]; if (ij < wb) b1 = Jbuf[pb + wb * (4 + g) + ij]; }
       acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
       if (dd > 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 0);
     }
@@ -909,6 +911,7 @@ struct RhsView {
   const int64_t* pi_a;     // offset of A (d x 6)
   const int64_t* pi_b;     // offset of b
   const int8_t* pi_d;
+  const int8_t* pi_w;      // columns of A (6, or 3 for a point kept in the reduced system)
   const int32_t* pe_ptr;   // [n_pose+1] pose-edge incidence
   const int32_t* pe_edge;
   const int32_t* e_point;
@@ -925,10 +928,10 @@ __global__ __launch_bounds__(256) void k_rhs(RhsView R, const double* const* __r
   for (int k = R.pi_ptr[a] + lane; k < R.pi_ptr[a + 1]; k += 64) {
     const double* A = Jbuf + R.pi_a[k];
     const double* b = Jbuf + R.pi_b[k];
-    const int d = R.pi_d[k];
+    const int d = R.pi_d[k], w = R.pi_w[k];
     for (int r = 0; r < d; ++r)
 #pragma unroll
-      for (int c = 0; c < 6; ++c) g[c] += A[r * 6 + c] * b[r];
+      for (int c = 0; c < 6; ++c) if (c < w) g[c] += A[r * w + c] * b[r];
   }
   for (int k = R.pe_ptr[a] + lane; k < R.pe_ptr[a + 1]; k += 64) {
     const int e = R.pe_edge[k];
@@ -1255,6 +1258,7 @@ __global__ void k_backsub_points(PointEdgeView V, const double* __restrict__ Z, 
                                  const double* __restrict__ uq, const double* __restrict__ dpose, double* __restrict__ dpoint) {
   const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= V.n_point) return;
+  if (V.chained && V.chained[q] == 2) return;   // kept in the reduced system: its update comes from there (k_rp_scatter)
   double s0 = uq[3 * q], s1 = uq[3 * q + 1], s2 = uq[3 * q + 2];
   for (int e = V.qe_ptr[q]; e < V.qe_ptr[q + 1]; ++e) {
     const double* z = Z + 18 * (int64_t)e;
@@ -1262,7 +1266,7 @@ __global__ void k_backsub_points(PointEdgeView V, const double* __restrict__ Z, 
 #pragma unroll
     for (int i = 0; i < 6; ++i) { s0 -= z[i * 3] * d[i]; s1 -= z[i * 3 + 1] * d[i]; s2 -= z[i * 3 + 2] * d[i]; }
   }
-  if (V.chained && V.chained[q]) {   // k_chain_backsub finishes along the chain
+  if (V.chained && V.chained[q] == 1) {   // k_chain_backsub finishes along the chain
     dpoint[3 * q] = s0; dpoint[3 * q + 1] = s1; dpoint[3 * q + 2] = s2;
     return;
   }
@@ -1278,6 +1282,15 @@ __global__ void k_mask_values(const double* __restrict__ poses, const double* __
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < 12 * n_pose) out[i] = mine_pose[i / 12] ? poses[i] : 0.0;
   else if (i < 12 * n_pose + 3 * n_point) { const int64_t j = i - 12 * n_pose; out[i] = mine_point[j / 3] ? points[j] : 0.0; }
+}
+
+// points that are NOT Schur-eliminated (they carry a dense prior / are retained by a marginalisation) ride in the reduced
+// system as 6-wide pseudo-poses whose last three rows are padding; their update is the first half of that block
+__global__ void k_rp_scatter(int64_t n_rp, const int32_t* __restrict__ rp_pose, const int32_t* __restrict__ rp_point, const double* __restrict__ dpose,
+                             double* __restrict__ dpoint) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 3 * n_rp) return;
+  dpoint[3 * (int64_t)rp_point[i / 3] + i % 3] = dpose[6 * (int64_t)rp_pose[i / 3] + i % 3];
 }
 
 __global__ void k_retract(const double* __restrict__ poses, const double* __restrict__ points, const double* __restrict__ dpose,
@@ -1306,6 +1319,7 @@ struct PriorView {
   const double* eta;
   const double* lin;      // [n*12]
   const int32_t* pose;    // [n] pose index (sorted space)
+  const int32_t* ptq;     // [n] point index if the variable is a Point3 (padded to 6 rows here), else -1
   double c;
 };
 
@@ -1330,7 +1344,8 @@ __device__ __forceinline__ double prior_q(const PriorView& P, const double* __re
   return q;
 }
 
-__global__ __launch_bounds__(256) void k_prior(PriorView P, int mode, const double* __restrict__ poses, const double* const* __restrict__ dx0_pp,
+__global__ __launch_bounds__(256) void k_prior(PriorView P, int mode, const double* __restrict__ poses, const double* __restrict__ points,
+                                               const double* const* __restrict__ dx0_pp,
                                                const double* __restrict__ dpose, double* __restrict__ dx_out, double* __restrict__ g_out,
                                                double* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) double sh[];
@@ -1348,8 +1363,10 @@ __global__ __launch_bounds__(256) void k_prior(PriorView P, int mode, const doub
     return;
   }
   for (int k = threadIdx.x; k < P.n; k += 256) {
-    double xi[6];
-    local(load_pose(P.lin + 12 * k), load_pose(poses + 12 * (int64_t)P.pose[k]), xi);
+    double xi[6] = {0, 0, 0, 0, 0, 0};
+    const int32_t q = P.ptq[k];
+    if (q >= 0) { for (int c = 0; c < 3; ++c) xi[c] = points[3 * (int64_t)q + c] - P.lin[12 * k + c]; }
+    else local(load_pose(P.lin + 12 * k), load_pose(poses + 12 * (int64_t)P.pose[k]), xi);
 #pragma unroll
     for (int c = 0; c < 6; ++c) d[6 * k + c] = xi[c];
   }

@@ -1,0 +1,339 @@
+"""Incremental HYBRID-formulation graph builder on flat arrays: the per-frame update functions of the
+reference, restated without GTSAM objects.  One `update(packet)` = one backend spin of RegularBackendModule::nominalSpinImpl
+(dynosam/src/backend/RegularBackendModule.cc:176-214): addStates, updateStaticObservations, updateDynamicObservations with
+`do_backtrack = false` (:197-198).  Factors are appended in the reference's insertion order, so `slot` = position in the
+caller's NonlinearFactorGraph (Formulation-impl.hpp:625).
+
+Restated functions
+  * updateMapWithMeasurements (RegularBackendModule.cc:572-...) / Map bookkeeping: node sets ordered by id
+    (dynosam_opt/include/dynosam_opt/MapNodes.hpp:76-100)
+  * addInitialVisualState / addVisualInertialStates without IMU (VisionImuBackendModule.hpp:88-243): pose value; prior on the
+    first pose; odometry BetweenFactor from the frontend's T_{k-1,k}
+  * StaticFormulationUpdater::PTP::addLandmark (Formulation-impl.hpp:145-235): a static tracklet enters at the frame its
+    observation count reaches min_static_observations - with only THAT frame's factor when do_backtrack is false - and is
+    initialised there by T_W_X * z; afterwards one PoseToPointFactor per frame
+  * Formulation::updateDynamicObservations (Formulation-impl.hpp:604-897): objects seen at k and before, >= min_dynamic_observations
+    landmarks in both frames; a tracklet enters once it has min_dynamic_observations observations, with the pair (its previous
+    seen frame, k); afterwards one factor per frame; then, per affected (object, frame): motion value, keyframe prior, smoothing
+  * HybridFormulation::dynamicPointUpdateCallback / objectUpdateContext (HybridEstimator.cc:573-811)
+  * RegularHybridFormulation::preUpdate / postUpdate (HybridEstimator.cc:1160-1222): re-appearing objects start a new keyframe
+  * HybridFormulationV1::getIntermediateMotionInfo / getOrConstructL0 / forceNewKeyFrame / computeInitialH /
+    calculateObjectCentroid (HybridEstimator.cc:866-1160): the object's keyframe is the first frame the formulation asks about
+    (k-1 of the first factor pair), L_e = (I, centroid of its points there in the world); initial eH_k = frontend F2F motion
+    composed with the current estimate of eH_{k-1}; a gap of more than 2 frames starts a new keyframe
+Not restated: IMU states, the GenericProjection/stereo static updaters, ground-truth initialisation of L_e.
+The batch builder of dynosam_amd/tracks.py stays as the simplified cross-check."""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import symbols as S
+from .graph import (F_BETWEEN_POSE3, F_HYBRID_MOTION, F_HYBRID_SMOOTHING, F_POSE_TO_POINT, F_PRIOR_POSE3, VAR_POINT3, VAR_POSE3,
+                    FactorBlock, FlatGraph)
+from .synth import act, compose, from12, inverse, to12
+from .tracks import BackendParams
+
+IDENTITY = (np.eye(3), np.zeros(3))
+
+
+@dataclass
+class FramePacket:
+    """What one VisionImuPacket contributes (camera-frame 3-D measurements, frontend motion estimates)."""
+    frame_id: int
+    X_world: np.ndarray                         # [12] initial sensor pose T_world_camera (frontend estimate)
+    T_k_1_k: np.ndarray | None = None           # [12] odometry from the previous frame; None at the first frame
+    static: np.ndarray = field(default_factory=lambda: np.zeros((0, 4)))     # rows (tracklet, x, y, z)
+    dynamic: np.ndarray = field(default_factory=lambda: np.zeros((0, 5)))    # rows (tracklet, object, x, y, z)
+    motions: dict = field(default_factory=dict)  # object -> [12] H_W_{k-1,k} (frame-to-frame, global)
+
+
+class HybridFormulation:
+    def __init__(self, params: BackendParams | None = None, use_smoothing_factor=True, use_vo=True):
+        self.p = params or BackendParams()
+        self.use_smoothing_factor, self.use_vo = use_smoothing_factor, use_vo
+        # ---- map (MapNodes.hpp): everything iterates in id order ----
+        self.frames = []                          # frame ids in arrival order
+        self.X_init = {}                          # frame -> pose
+        self.static_meas = {}                     # tracklet -> {frame: z}
+        self.dyn_meas = {}                        # tracklet -> {frame: z}
+        self.dyn_object = {}                      # tracklet -> object
+        self.frame_static = {}                    # frame -> sorted tracklets
+        self.frame_objects = {}                   # frame -> sorted objects seen
+        self.obj_frames = {}                      # object -> sorted frames seen
+        self.obj_lmks_at = {}                     # (object, frame) -> sorted tracklets
+        self.frontend_motion = {}                 # (frame, object) -> pose
+        # ---- formulation state ----
+        self.theta = {}                           # key -> state (12 doubles; points use the first 3)
+        self.vtype = {}
+        self.factors = []                         # (type, keys, meas, noise, huber, consts) in slot order
+        self.static_added = set()
+        self.dyn_in_map = {}                      # tracklet -> keyframe id (is_dynamic_tracklet_in_map_)
+        self.other_values_in_map = set()          # motion keys
+        self.smoothing_added = set()
+        self.key_frames = {}                      # object -> list of [start, end, L_e] (end None = active range)
+        self.objects_update_data = {}             # object -> frame of its last dynamic update (RegularHybridFormulation)
+        self._new_keys = []
+
+    # ------------------------------------------------------------------ helpers
+    def _add_factor(self, ftype, keys, meas=(), noise=(), hk=0.0, consts=()):
+        self.factors.append((ftype, [np.uint64(k) for k in keys], np.asarray(meas, float), np.asarray(noise, float), float(hk), np.asarray(consts, float)))
+
+    def _insert(self, key, state12, vtype):
+        key = int(key)
+        assert key not in self.theta, "ValuesKeyAlreadyExists"
+        self.theta[key] = np.asarray(state12, float).copy()
+        self.vtype[key] = vtype
+        self._new_keys.append(key)
+
+    def _pose(self, key):
+        return from12(self.theta[int(key)])
+
+    def sensor_pose(self, frame):
+        """getInitialOrLinearizedSensorPose: the current estimate if the pose is in theta, else the initial one."""
+        k = int(S.CameraPoseSymbol(frame))
+        return from12(self.theta[k]) if k in self.theta else self.X_init[frame]
+
+    def _iso6(self, sr, st):
+        return [sr] * 3 + [st] * 3
+
+    # ------------------------------------------------------------------ key frames (KeyFrameData)
+    def _find_range(self, obj, frame):
+        for r in self.key_frames.get(obj, []):
+            if r[0] <= frame and (r[1] is None or frame < r[1]):
+                return r
+        return None
+
+    def _centroid(self, obj, frame):
+        """calculateObjectCentroid (HybridEstimator.cc:1093-1160): mean of the object's measurements at `frame`, in the world."""
+        X = self.sensor_pose(frame)
+        pts = np.array([self.dyn_meas[t][frame] for t in self.obj_lmks_at[(obj, frame)]])
+        return (np.eye(3), act(X, pts.mean(0)))
+
+    def _force_new_key_frame(self, frame, obj):
+        rs = self.key_frames.setdefault(obj, [])
+        if rs and rs[-1][1] is None:
+            rs[-1][1] = frame
+        rs.append([frame, None, self._centroid(obj, frame)])
+        return rs[-1]
+
+    def _get_or_construct_L0(self, obj, frame):
+        r = self._find_range(obj, frame)
+        return r if r is not None else self._force_new_key_frame(frame, obj)
+
+    def _compute_initial_H(self, obj, frame):
+        s0 = self._get_or_construct_L0(obj, frame)[0]
+        cur = frame
+        if cur == s0:
+            return IDENTITY
+        if (cur, obj) not in self.frontend_motion:
+            prev = [f for f in self.obj_frames[obj] if f < cur]
+            assert prev and prev[-1] > s0, "bookkeeping failure (HybridEstimator.cc:960-975)"
+            if cur - prev[-1] > 2:
+                self._force_new_key_frame(frame, obj)
+                return IDENTITY
+            cur = prev[-1]
+        m = self.frontend_motion[(cur, obj)]
+        if cur - 1 == s0:
+            return m
+        km1 = int(S.ObjectMotionSymbol(obj, frame - 1))
+        if km1 in self.theta:                       # estimate of eH_{k-1} (accessor->getEstimatedMotion)
+            return compose(m, from12(self.theta[km1]))
+        H = IDENTITY
+        for f in range(s0 + 1, cur + 1):            # compose the frontend's frame-to-frame motions
+            if (f, obj) not in self.frontend_motion:
+                break
+            H = compose(self.frontend_motion[(f, obj)], H)
+        return H
+
+    def _motion_info(self, obj, frame):
+        H = self._compute_initial_H(obj, frame)
+        r = self._get_or_construct_L0(obj, frame)
+        return r[0], r[2], H
+
+    # ------------------------------------------------------------------ one backend spin
+    def update(self, pk: FramePacket):
+        k = int(pk.frame_id)
+        n0 = len(self.factors)
+        self._new_keys = []
+        X_k = from12(np.asarray(pk.X_world, float))
+        # ---- addStates ----
+        first = not self.frames
+        self.frames.append(k)
+        self.X_init[k] = X_k
+        self._insert(S.CameraPoseSymbol(k), to12(X_k), VAR_POSE3)
+        if first:
+            self._add_factor(F_PRIOR_POSE3, [S.CameraPoseSymbol(k)], to12(X_k), self._iso6(self.p.prior_sigma, self.p.prior_sigma))
+        elif self.use_vo:
+            assert pk.T_k_1_k is not None
+            self._add_factor(F_BETWEEN_POSE3, [S.CameraPoseSymbol(self.frames[-2]), S.CameraPoseSymbol(k)], np.asarray(pk.T_k_1_k, float),
+                             self._iso6(self.p.odometry_rotation_sigma, self.p.odometry_translation_sigma))
+        # ---- updateMapWithMeasurements ----
+        st = np.asarray(pk.static, float).reshape(-1, 4)
+        dy = np.asarray(pk.dynamic, float).reshape(-1, 5)
+        for row in st:
+            self.static_meas.setdefault(int(row[0]), {})[k] = row[1:4]
+        self.frame_static[k] = sorted(set(int(t) for t in st[:, 0]))
+        objs = set()
+        for row in dy:
+            t, j = int(row[0]), int(row[1])
+            self.dyn_meas.setdefault(t, {})[k] = row[2:5]
+            self.dyn_object[t] = j
+            objs.add(j)
+            self.obj_lmks_at.setdefault((j, k), []).append(t)
+        for j in objs:
+            self.obj_lmks_at[(j, k)] = sorted(set(self.obj_lmks_at[(j, k)]))
+            self.obj_frames.setdefault(j, []).append(k)
+        self.frame_objects[k] = sorted(objs)
+        for j, m in pk.motions.items():
+            self.frontend_motion[(k, int(j))] = from12(np.asarray(m, float))
+        # ---- RegularHybridFormulation::preUpdate (HybridEstimator.cc:1160-1190): a known object that re-appears after a
+        # frame without update starts a new keyframe ----
+        for j in self.frame_objects[k]:
+            if j in self.objects_update_data and self.obj_frames[j][0] != k and k > 0 and self.objects_update_data[j] < k - 1:
+                self._force_new_key_frame(k, j)
+        self._update_static(k)
+        affected = self._update_dynamic(k)
+        for j, fs in affected.items():            # postUpdate (:1198-1222)
+            assert k in fs
+            self.objects_update_data[j] = k
+        return n0, len(self.factors)
+
+    def _point_noise(self, sigma):
+        return np.eye(3).reshape(-1) / sigma
+
+    def _update_static(self, k):
+        p = self.p
+        hub = p.k_huber_3d_points if p.use_robust_kernels else 0.0
+        Rs = self._point_noise(p.static_point_noise_sigma)
+        Xk = S.CameraPoseSymbol(k)
+        for t in self.frame_static[k]:
+            pkey = S.StaticLandmarkSymbol(t)
+            z = self.static_meas[t][k]
+            if t in self.static_added:
+                self._add_factor(F_POSE_TO_POINT, [Xk, pkey], z, Rs, hub)
+                continue
+            if len(self.static_meas[t]) < p.min_static_observations:
+                continue
+            # first time with enough observations; do_backtrack = false: only the current frame's factor (:186-189)
+            self._add_factor(F_POSE_TO_POINT, [Xk, pkey], z, Rs, hub)
+            self._insert(pkey, np.concatenate([act(self.X_init[k], z), np.zeros(9)]), VAR_POINT3)   # hasInitialSensorPose(frame_k)
+            self.static_added.add(t)
+
+    def _update_dynamic(self, k):
+        p = self.p
+        hub = p.k_huber_3d_points if p.use_robust_kernels else 0.0
+        Rd = self._point_noise(p.dynamic_point_noise_sigma)
+        affected = {}                                  # object -> set of frames (result.objects_affected_per_frame)
+
+        def point_update(t, obj, f1, f, starting):
+            """HybridFormulation::dynamicPointUpdateCallback"""
+            s0, L_e, H_init = self._motion_info(obj, f1)
+            mkey = S.HybridDynamicKey(t)
+            if t not in self.dyn_in_map:
+                self.dyn_in_map[t] = s0
+                m0 = act(inverse(L_e), act(inverse(H_init), act(self.sensor_pose(f1), self.dyn_meas[t][f1])))   # projectToObject3
+                self._insert(mkey, np.concatenate([m0, np.zeros(9)]), VAR_POINT3)
+                affected.setdefault(obj, set()).add(f1)
+            if starting:
+                self._add_factor(F_HYBRID_MOTION, [S.CameraPoseSymbol(f1), S.ObjectMotionSymbol(obj, f1), mkey], self.dyn_meas[t][f1], Rd, hub, to12(L_e))
+            self._add_factor(F_HYBRID_MOTION, [S.CameraPoseSymbol(f), S.ObjectMotionSymbol(obj, f), mkey], self.dyn_meas[t][f], Rd, hub, to12(L_e))
+            affected.setdefault(obj, set()).add(f)
+
+        for obj in self.frame_objects[k]:
+            seen = self.obj_frames[obj]
+            if len(seen) < 2:
+                continue                               # not seen twice
+            last_seen = seen[-2]
+            lm_k = self.obj_lmks_at[(obj, k)]
+            if len(lm_k) < p.min_dynamic_observations or len(self.obj_lmks_at[(obj, last_seen)]) < p.min_dynamic_observations:
+                continue
+            for t in lm_k:
+                frames_t = sorted(self.dyn_meas[t])
+                if len(frames_t) < p.min_dynamic_observations:
+                    continue
+                if t not in self.dyn_in_map:
+                    if k < frames_t[0] + 1:
+                        continue
+                    i = frames_t.index(k)              # do_backtrack = false: start at the requested frame
+                    point_update(t, obj, frames_t[i - 1], k, True)
+                else:
+                    point_update(t, obj, last_seen, k, False)
+        # ---- objects for which a motion was touched (Formulation-impl.hpp:835-879) ----
+        for obj in sorted(affected):
+            for idx, f in enumerate(sorted(affected[obj])):
+                self._object_update(obj, f)
+        return affected
+
+    def _object_update(self, obj, f):
+        """HybridFormulation::objectUpdateContext"""
+        p = self.p
+        Hk = S.ObjectMotionSymbol(obj, f)
+        s0, L_e, H_init = self._motion_info(obj, f)
+        if int(Hk) not in self.other_values_in_map:
+            self._insert(Hk, to12(H_init), VAR_POSE3)
+            self.other_values_in_map.add(int(Hk))
+            if s0 == f:
+                self._add_factor(F_PRIOR_POSE3, [Hk], to12(IDENTITY), self._iso6(p.prior_sigma, p.prior_sigma))
+        if f < 2 or (f - 1) not in self.frame_objects or (f - 2) not in self.frame_objects:
+            return
+        if self.use_smoothing_factor and obj in self.frame_objects[f - 1] and obj in self.frame_objects[f - 2]:
+            H1, H2 = S.ObjectMotionSymbol(obj, f - 1), S.ObjectMotionSymbol(obj, f - 2)
+            if int(Hk) not in self.smoothing_added and all(int(x) in self.other_values_in_map for x in (H2, H1, Hk)):
+                self._add_factor(F_HYBRID_SMOOTHING, [H2, H1, Hk], (), self._iso6(p.constant_object_motion_rotation_sigma, p.constant_object_motion_translation_sigma),
+                                 0.0, to12(L_e))
+                self.smoothing_added.add(int(Hk))
+
+    # ------------------------------------------------------------------ export
+    def _blocks(self, lo, hi, index=None):
+        rows = {}
+        for slot in range(lo, hi):
+            ftype, fk, meas, noise, hk, consts = self.factors[slot]
+            rows.setdefault(ftype, []).append((slot, [index[int(x)] for x in fk] if index is not None else [int(x) for x in fk], meas, noise, hk, consts))
+        out = []
+        for ftype in (F_PRIOR_POSE3, F_BETWEEN_POSE3, F_POSE_TO_POINT, F_HYBRID_MOTION, F_HYBRID_SMOOTHING):
+            rws = rows.get(ftype)
+            if not rws:
+                continue
+            out.append((ftype, np.array([r[0] for r in rws]), np.array([r[1] for r in rws], dtype=np.int64 if index is not None else np.uint64),
+                        np.array([r[2] for r in rws]), np.array([r[3] for r in rws]),
+                        np.array([r[4] for r in rws]) if any(r[4] > 0 for r in rws) else None, np.array([r[5] for r in rws]) if rws[0][5].size else None))
+        return out
+
+    def new_values_and_factors(self, span):
+        """(new_values, new_factors) of one spin in key space: what RegularBackendModule hands to
+        SlidingWindowOptimization::update (RegularBackendModule.cc:300-330) - see dynosam_amd/sliding_window.py."""
+        from .sliding_window import KeyedBlock
+        vals = {k: (int(self.vtype[k]), self.theta[k].copy()) for k in self._new_keys}
+        return vals, [KeyedBlock(*b) for b in self._blocks(span[0], span[1])]
+
+    def set_values(self, keys, states):
+        """updateTheta(optimised): values estimated by the optimiser become the linearisation points of later spins."""
+        for key, s in zip(keys, states):
+            self.theta[int(key)][:] = s
+
+    def graph(self) -> FlatGraph:
+        keys = np.array(sorted(self.theta), dtype=np.uint64)
+        index = {int(k): i for i, k in enumerate(keys)}
+        vtype = np.array([self.vtype[int(k)] for k in keys], dtype=np.uint8)
+        state = np.array([self.theta[int(k)] for k in keys]).reshape(len(keys), 12)
+        blocks = [FactorBlock(*b) for b in self._blocks(0, len(self.factors), index)]
+        return FlatGraph(keys, vtype, state, blocks, dict(frames=len(self.frames), objects=len(self.key_frames), n_factors=len(self.factors)))
+
+
+def packets_from_arrays(frames, X_world, observations, motions):
+    """The array form of tests/golden/small_frontend_tracks.npz (and of dynosam_amd/tracks.py) -> FramePackets."""
+    frames = [int(f) for f in frames]
+    X = np.asarray(X_world, float)
+    obs = np.asarray(observations, float)
+    mot = np.asarray(motions, float).reshape(-1, 14)
+    out = []
+    for i, f in enumerate(frames):
+        o = obs[obs[:, 0] == f]
+        st, dy = o[o[:, 2] <= 0], o[o[:, 2] > 0]
+        T = None
+        if i:
+            T = to12(compose(inverse(from12(X[i - 1])), from12(X[i])))
+        out.append(FramePacket(f, X[i], T, st[:, [1, 3, 4, 5]], dy[:, [1, 2, 3, 4, 5]], {int(m[1]): m[2:] for m in mot if int(m[0]) == f}))
+    return out

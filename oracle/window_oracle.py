@@ -93,7 +93,8 @@ class WindowOracle:
     def prior_terms(self, state):
         """(dx, gradient eta - Lambda dx, value Q(dx)) of the dense prior"""
         P = self.g.prior
-        dx = np.concatenate([_local(P.lin_state[k], state[v]) for k, v in enumerate(self.prior_var)])
+        # Local(lin, x): Pose3 -> 6-vector, Point3 -> x - lin (the prior may name both, GTSAM marginals are on any variable)
+        dx = np.concatenate([_local(P.lin_state[k], state[v]) if self.dims[v] == 6 else state[v, :3] - P.lin_state[k, :3] for k, v in enumerate(self.prior_var)])
         v = P.Lambda @ dx
         return dx, P.eta - v, 0.5 * dx @ v - P.eta @ dx + P.c
 
@@ -118,7 +119,7 @@ class WindowOracle:
                     H[o1:o1 + A[s1].shape[1], o2:o2 + A[s2].shape[1]] += A[s1].T @ A[s2]
         if self.prior_var is not None:
             dx, gp, q = self.prior_terms(state)
-            idx = np.concatenate([np.arange(self.off[v], self.off[v] + 6) for v in self.prior_var])
+            idx = np.concatenate([np.arange(self.off[v], self.off[v] + self.dims[v]) for v in self.prior_var])
             H[np.ix_(idx, idx)] += self.g.prior.Lambda
             g[idx] += gp
             c += q
@@ -219,7 +220,7 @@ class WindowOracle:
         if self.prior_var is not None:
             dx, gp, q = self.prior_terms(state)
             if prior_touch:
-                idx = np.concatenate([np.arange(self.off[v], self.off[v] + 6) for v in self.prior_var])
+                idx = np.concatenate([np.arange(self.off[v], self.off[v] + self.dims[v]) for v in self.prior_var])
                 H[np.ix_(idx, idx)] += g.prior.Lambda
                 gv[idx] += gp
                 c += q
@@ -230,7 +231,6 @@ class WindowOracle:
             return blocks, None
         M = np.concatenate([np.arange(self.off[v], self.off[v + 1]) for v in np.nonzero(touched & is_m)[0]])
         sv = np.nonzero(touched & ~is_m)[0]
-        assert (self.dims[sv] == 6).all(), "retained point adjacent to a marginalised variable"
         S = np.concatenate([np.arange(self.off[v], self.off[v + 1]) for v in sv]) if len(sv) else np.zeros(0, int)
         Lm = np.linalg.cholesky(H[np.ix_(M, M)])
         Y = np.linalg.solve(Lm, H[np.ix_(M, S)])

@@ -121,3 +121,86 @@ def test_streaming_driver_runs_windows_like_the_reference_loop():
             assert not (set(int(kk) for kk in r.prior.keys) & sw.marginalized)
             assert all(b.type & F_LINEARIZED for b in r.prior_blocks)
     assert fired == [10, 17]
+
+
+def mixed_keys(g, pose_cut, point_cut):
+    """old pose-like variables and only the OLDEST points: the younger points observed from marginalised poses stay in the
+    window - retained Point3 variables next to marginalised ones, which the marginal must then name"""
+    vt, vf = g.var_type, g.meta["var_frame"]
+    return [int(k) for k, t, f in zip(g.var_keys, vt, vf) if (t == 0 and f < pose_cut) or (t != 0 and f < point_cut)]
+
+
+def test_marginal_with_retained_points_matches_oracle():
+    from dynosam_amd.optimizer import Context
+    g = tiny(seed=8)
+    c = Context(); c.upload(g)
+    keys = mixed_keys(g, 4, 2)
+    blocks, prior = c.marginalize(keys)
+    rblocks, rprior = WO.WindowOracle(g).marginalize(keys, g.var_state)
+    assert np.array_equal(prior.keys, rprior.keys)
+    n_pt = int((g.var_type[[g.key_index(int(k)) for k in prior.keys]] != 0).sum())
+    assert n_pt > 0 and prior.Lambda.shape == rprior.Lambda.shape == (6 * (len(prior.keys) - n_pt) + 3 * n_pt,) * 2
+    sc = np.abs(rprior.Lambda).max()
+    assert np.abs(prior.Lambda - rprior.Lambda).max() <= 1e-8 * sc
+    assert np.abs(prior.eta - rprior.eta).max() <= 1e-8 * max(1.0, np.abs(rprior.eta).max())
+    assert abs(prior.c - rprior.c) <= 1e-8 * max(1.0, abs(rprior.c))
+    assert sum(b.count for b in blocks) == sum(b.count for b in rblocks)
+    c.close()
+
+
+def test_lm_with_a_prior_on_points_matches_oracle():
+    from dynosam_amd.optimizer import Context
+    g = tiny(seed=9)
+    keys = mixed_keys(g, 4, 2)
+    rblocks, rprior = WO.WindowOracle(g).marginalize(keys, g.var_state)
+    g2 = carry(g, keys, rblocks, rprior, g.var_state)
+    w2 = WO.WindowOracle(g2)
+    rng = np.random.default_rng(2)
+    x0 = w2.retract(g2.var_state, 0.02 * rng.normal(size=w2.n))
+    g2 = g2.with_state(x0)
+    w2 = WO.WindowOracle(g2)
+    c = Context(); c.upload(g2)
+    e_ref = w2.error(x0)
+    assert abs(c.error() - e_ref) <= 1e-9 * max(1.0, e_ref)
+    d, dec = c.solve_damped(1e-3)                      # one damped solve: the kept points ride in the reduced system
+    dref = w2.solve_damped(x0, 1e-3) if hasattr(w2, "solve_damped") else None
+    if dref is not None:
+        assert np.abs(d - dref).max() <= 1e-6 * max(1.0, np.abs(dref).max())
+    rep = c.optimize()
+    rr, trace = w2.optimize()
+    assert rep.iterations == rr.iterations and rep.inner_iterations == rr.inner_iterations
+    assert [bool(rep.trace_accepted[i]) for i in range(rep.trace_len)] == [t[2] for t in trace]
+    assert abs(rep.error_after - rr.error_after) <= 1e-6 * max(rr.error_after, 1e-12)
+    assert np.abs(c.values() - w2.state).max() <= 1e-5
+    # and marginalising again from a state that carries a prior on points (prior touched and untouched paths)
+    c.set_values(g2.var_state)
+    k2 = [int(k) for k in g2.var_keys[:6]]
+    blocks, prior = c.marginalize(k2)
+    rb, rp = WO.WindowOracle(g2).marginalize(k2, g2.var_state)
+    assert np.array_equal(prior.keys, rp.keys)
+    assert np.abs(prior.Lambda - rp.Lambda).max() <= 1e-8 * np.abs(rp.Lambda).max()
+    assert np.abs(prior.eta - rp.eta).max() <= 1e-8 * max(1.0, np.abs(rp.eta).max())
+    assert abs(prior.c - rp.c) <= 1e-8 * max(1.0, abs(rp.c))
+    c.close()
+
+
+def test_marginalising_points_the_old_prior_names():
+    """second window: Point3 variables that carry the dense prior are themselves marginalised (they are eliminated by the
+    tile factorisation of the scratch graph, not by the point Schur complement)"""
+    from dynosam_amd.optimizer import Context
+    g = tiny(seed=10)
+    k1 = mixed_keys(g, 3, 1)
+    b1, p1 = WO.WindowOracle(g).marginalize(k1, g.var_state)
+    g2 = carry(g, k1, b1, p1, g.var_state)
+    prior_pts = [int(k) for k in p1.keys if g2.var_type[g2.key_index(int(k))] != 0]
+    assert len(prior_pts) >= 2
+    old_poses = [int(k) for k in g2.var_keys if int(k) in set(mixed_keys(g, 5, 0))]
+    k2 = sorted(set(prior_pts[: len(prior_pts) // 2 + 1] + old_poses))
+    c = Context(); c.upload(g2)
+    blocks, prior = c.marginalize(k2)
+    rb, rp = WO.WindowOracle(g2).marginalize(k2, g2.var_state)
+    assert np.array_equal(prior.keys, rp.keys) and not (set(int(k) for k in prior.keys) & set(k2))
+    assert np.abs(prior.Lambda - rp.Lambda).max() <= 1e-8 * np.abs(rp.Lambda).max()
+    assert np.abs(prior.eta - rp.eta).max() <= 1e-8 * max(1.0, np.abs(rp.eta).max())
+    assert abs(prior.c - rp.c) <= 1e-8 * max(1.0, abs(rp.c))
+    c.close()

@@ -72,6 +72,7 @@ class SWOptimizationResult:
     prior: Optional[LinearPrior] = None
     report: object = None
     graph: Optional[FlatGraph] = None
+    timings_ms: Optional[Dict[str, float]] = None
 
 
 class SlidingWindowOptimization:
@@ -114,22 +115,31 @@ class SlidingWindowOptimization:
         return key in self.key_frame and self.key_frame[key] > self.current_frame - self.overlap
 
     def optimize_window(self) -> SWOptimizationResult:
+        import time
+        t0 = time.perf_counter()
         blocks = self._filter_valid(self.blocks) + self.prior_blocks
         g = flatten(self.values, blocks, self.prior)
+        t1 = time.perf_counter()
         self.ctx.upload(g)
+        t2 = time.perf_counter()
         rep = self.ctx.optimize(self.params)
+        t3 = time.perf_counter()
         st = self.ctx.values()
         result = {int(k): (int(g.var_type[i]), st[i].copy()) for i, k in enumerate(g.var_keys)}
         retained = {k: v for k, v in result.items() if self.is_recent(k)}
         to_marg = [k for k in result if k not in retained]
+        t4 = time.perf_counter()
         lin_blocks, prior = self.ctx.marginalize(to_marg)
+        t5 = time.perf_counter()
         self.prior_blocks = [keyed(b, g.var_keys) for b in lin_blocks]
         self.prior = prior
         self.marginalized.update(to_marg)
         self.frame_window = self.frame_window[-self.overlap:] if self.overlap else []
         self.blocks = []
         self.values = retained
-        return SWOptimizationResult(True, result, self.prior_blocks, self.prior, rep, g)
+        tm = dict(flatten=1e3 * (t1 - t0), upload=1e3 * (t2 - t1), optimize=1e3 * (t3 - t2), download=1e3 * (t4 - t3), marginalize=1e3 * (t5 - t4),
+                  bookkeeping=1e3 * (time.perf_counter() - t5))
+        return SWOptimizationResult(True, result, self.prior_blocks, self.prior, rep, g, tm)
 
 
 def frame_stream(g: FlatGraph):

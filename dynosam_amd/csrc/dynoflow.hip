@@ -248,6 +248,7 @@ __global__ void k_gray_u8(const uint8_t* __restrict__ rgb, int n, uint8_t* __res
   out[i] = (uint8_t)((rgb[3 * i] * 4899 + rgb[3 * i + 1] * 9617 + rgb[3 * i + 2] * 1868 + (1 << 13)) >> 14);
 }
 __device__ __forceinline__ int reflect101(int i, int n) {
+  if ((unsigned)i < (unsigned)n) return i;   // interior: no integer division on the hot path
   if (n == 1) return 0;
   const int p = 2 * (n - 1);
   i %= p;

@@ -104,6 +104,7 @@ def main():
 
     ctx = Context(device=local_rank, world_size=world, rank=rank, allreduce=allreduce if collective else None,
                   stream=stream.cuda_stream)
+    ctx.set_profiling(True)   # per-segment HIP-event times for the roofline block (costs the one-graph replay, ~2 %)
     ctx.upload(shard)
 
     def run(n_iter):

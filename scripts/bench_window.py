@@ -8,6 +8,7 @@ from dynosam_amd import synth, sliding_window as SW
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 72
 g = synth.make_hybrid_graph(synth.config(2, frames=frames, static_points=40 * frames, dynamic_points_per_object=2 * frames))
 sw = SW.SlidingWindowOptimization(window_size=20, overlap=4)
+sw.ctx.set_profiling(bool(os.environ.get('STATS')))
 print("stream:", frames, "frames,", g.n_factors, "factors")
 for k, blocks, vals in SW.frame_stream(g):
     t0 = time.perf_counter()

@@ -12,6 +12,7 @@ for cfgn, kw in [CASES[a] for a in sys.argv[1:]]:
     print(f"--- cfg {cfgn} {kw}: vars {g.n_vars} factors {g.n_factors}", flush=True)
     og = O.OracleGraph(g)
     ctx = Context()
+ctx.set_profiling(True)
     t = time.time(); ctx.upload(g); print("upload s", time.time() - t, "n", ctx.graph.n_vars, flush=True)
     e_gpu, e_ref = ctx.error(), og.error()
     print("error", e_gpu, e_ref, abs(e_gpu - e_ref) / e_ref, flush=True)

@@ -19,6 +19,7 @@ res = [None] * world
 def body(r):
     c = Context(device=0, world_size=world, rank=r, allreduce=fw.allreduce(r))
     c.set_graphs(False)
+    c.set_profiling(True)
     c.upload(g.shard(r, world))
     P = LevenbergMarquardtParams(); P.max_iterations = 6; P.relative_error_tol = 1e-300; P.absolute_error_tol = 0.0
     c.optimize(P); c.set_values(g.var_state); c.reset_kernel_stats()

@@ -9,6 +9,7 @@ n_solve = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 n_lm = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 g = synth.make_hybrid_graph(synth.config(int(os.environ.get("CFG", "2"))))
 ctx = Context()
+ctx.set_profiling(True)
 ctx.upload(g)
 if os.environ.get("NOSPEC"):
     ctx.set_speculation(False)

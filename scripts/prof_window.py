@@ -5,6 +5,7 @@ from dynosam_amd.optimizer import Context, LevenbergMarquardtParams
 g = synth.make_hybrid_graph(synth.config(2, frames=21, static_points=40 * 21, dynamic_points_per_object=2 * 21))
 print(g.n_factors, g.n_vars)
 ctx = Context()
+ctx.set_profiling(True)
 t = time.perf_counter(); ctx.upload(g); print("upload ms", 1e3 * (time.perf_counter() - t))
 for rep in range(3):
     ctx.set_values(g.var_state)

@@ -83,3 +83,26 @@ def test_unsorted_keys_are_rejected():
     g = synth.make_hybrid_graph(synth.config(1, frames=4, static_points=4, dynamic_points_per_object=2))
     with pytest.raises(ValueError):
         G.FlatGraph(g.var_keys[::-1].copy(), g.var_type[::-1].copy(), g.var_state[::-1].copy(), g.blocks)
+
+
+def test_config5_maximum_size_on_one_gpu():
+    """BASELINE config 5 (2 000 frames, 50 objects, 200 000 landmarks, 1.97 M factors - the size the reference quotes for 8
+    GPUs) as ONE context: size-independent properties of the LM trace, no oracle at this size."""
+    from dynosam_amd import synth
+    from dynosam_amd.optimizer import Context, LevenbergMarquardtParams
+    g = synth.make_hybrid_graph(synth.config(5))
+    assert g.n_factors > 1_900_000 and g.n_vars == 212_000
+    c = Context(); c.upload(g)
+    P = LevenbergMarquardtParams(); P.max_iterations = 4; P.relative_error_tol = 1e-300; P.absolute_error_tol = 0.0
+    r = c.optimize(P)
+    assert r.iterations == 4 and r.error_after < 1e-3 * r.error_before
+    acc = [float(r.trace_error[i]) for i in range(r.trace_len) if r.trace_accepted[i]]
+    assert all(b < a for a, b in zip([r.error_before] + acc[:-1], acc))            # cost monotone over accepted steps
+    assert abs(c.error() - r.error_after) <= 1e-9 * r.error_after                   # the reported cost is the cost of the values
+    v = c.values()
+    assert np.isfinite(v).all()
+    # noiseless copy of the same scenario: the ground truth is a fixed point at full size too
+    g0 = synth.make_hybrid_graph(synth.config(5, noise_scale=0.0))
+    c.upload(g0)
+    assert c.error() < 1e-12
+    c.close()

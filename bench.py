@@ -251,6 +251,29 @@ def frontend_bench(device, cpu=True, frames=50):
     kerr = np.linalg.norm(k0["cur"] - spts - sc["flow_gt"][ysb[pb], xsb[pb]], axis=1)[k0["status"] == 1]
     out["static_klt"] = {"points": 800, "ms_per_call": 1e3 * kdt, "tracked": int(k0["status"].sum()), "err_median_px": float(np.median(kerr)),
                          "note": "21x21 window, 4 levels forward / 5 reverse, 30 iterations max; bit-exact against oracle/klt_oracle.py"}
+    # per-object joint flow + pose refinement, 5 objects x 200 tracklets in one launch (OpticalFlowAndPoseOptimizer)
+    from dynosam_amd.synth import act, compose, inverse, se3_exp, to12
+    Kc = (554.0, 554.0, 0.0, 320.0, 240.0)
+    probs = []
+    for j in range(5):
+        Xp = se3_exp(rng.normal(0, 0.05, 6)); Xk = compose(Xp, se3_exp(np.array([0.01, -0.02, 0.005, 0.1, 0.05, 0.2])))
+        kpj = np.stack([rng.uniform(50, 590, 200), rng.uniform(50, 430, 200)], -1); dj = rng.uniform(4, 20, 200)
+        bp = lambda kp_, d_: d_ * np.array([(kp_[0] - Kc[3]) / Kc[0], (kp_[1] - Kc[4]) / Kc[1], 1.0])
+        pr = np.array([(lambda q: [Kc[0] * q[0] / q[2] + Kc[3], Kc[1] * q[1] / q[2] + Kc[4]])(act(inverse(Xk), act(Xp, bp(kpj[i], dj[i])))) for i in range(200)])
+        fl = pr - kpj + rng.normal(0, 0.3, (200, 2)); fl[:8] += 60.0
+        probs.append(dict(X_prev=to12(Xp), pose_init=to12(compose(Xk, se3_exp(rng.normal(0, 0.01, 6)))), kp_prev=kpj, depth=dj, flow=fl))
+    rr = t.refine_flow_pose(probs, Kc)
+    t2 = time.perf_counter()
+    for _ in range(20):
+        rr = t.refine_flow_pose(probs, Kc)
+    rdt = (time.perf_counter() - t2) / 20
+    out["object_refinement"] = {"objects": 5, "tracklets_per_object": 200, "ms_per_call": 1e3 * rdt, "lm_steps": [r["iterations"] for r in rr],
+                                "outliers": [int((~r["inlier"]).sum()) for r in rr], "note": "whole LM + outlier rounds of all objects in one launch"}
+    if cpu:
+        from oracle import refine_oracle as RO
+        c1 = time.perf_counter()
+        RO.FlowPoseProblem(Kc, probs[0]["X_prev"], probs[0]["pose_init"], probs[0]["kp_prev"], probs[0]["depth"], probs[0]["flow"]).optimize()
+        out["object_refinement"]["cpu_baseline_ms_per_object"] = 1e3 * (time.perf_counter() - c1)
     if cpu:
         from oracle import flow_oracle as FO
         c0 = time.perf_counter()

@@ -984,9 +984,15 @@ __global__ __launch_bounds__(256) void k_rhs(RhsView R, const double* const* __r
     const double* A = Jbuf + R.pi_a[k];
     const double* b = Jbuf + R.pi_b[k];
     const int d = R.pi_d[k], w = R.pi_w[k];
-    for (int r = 0; r < d; ++r)
+    if (w == 6) {   // pose slot (the common case): fixed stride, fully unrolled
+      for (int r = 0; r < d; ++r)
 #pragma unroll
-      for (int c = 0; c < 6; ++c) if (c < w) g[c] += A[r * w + c] * b[r];
+        for (int c = 0; c < 6; ++c) g[c] += A[r * 6 + c] * b[r];
+    } else {        // a point kept in the reduced system: 3 columns
+      for (int r = 0; r < d; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) g[c] += A[r * 3 + c] * b[r];
+    }
   }
   for (int k = R.pe_ptr[a] + lane; k < R.pe_ptr[a + 1]; k += 64) {
     const int e = R.pe_edge[k];

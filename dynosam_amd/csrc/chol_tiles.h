@@ -114,6 +114,14 @@ __device__ __forceinline__ void ct_store_frag(double* __restrict__ T, int bi, in
 #pragma unroll
   for (int r = 0; r < 4; ++r) T[16 * bi + lr + 4 * r + CT_LD * (16 * bj + lc)] = acc[r];
 }
+// accumulator fragment straight from a tile in global memory (leading dimension 32): four 8-byte loads per lane
+__device__ __forceinline__ ct_d4 ct_gload_frag(const double* __restrict__ G, int bi, int bj, int lane) {
+  const int lr = lane >> 4, lc = lane & 15;
+  ct_d4 acc;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] = G[16 * bi + lr + 4 * r + CT_TS * (16 * bj + lc)];
+  return acc;
+}
 __device__ __forceinline__ ct_d4 ct_load_frag(const double* __restrict__ T, int bi, int bj, int lane) {
   const int lr = lane >> 4, lc = lane & 15;
   ct_d4 acc;
@@ -279,8 +287,10 @@ __global__ __launch_bounds__(256) void k_chol_level(CholLevelArgs a, int task0, 
   __shared__ __attribute__((aligned(16))) double XA[CT_TILE_LDS];
   __shared__ __attribute__((aligned(16))) double XB[CT_TILE_LDS];
   __shared__ __attribute__((aligned(16))) double LI[CT_TILE_LDS];
-  __shared__ __attribute__((aligned(16))) double Pt[CT_TILE_LDS];
-  __shared__ __attribute__((aligned(16))) double Qt[CT_TILE_LDS];
+  // the products P, Q overwrite their own operands (a barrier separates the last operand read from the first product
+  // write): three tile buffers instead of five - LDS was what limited the workgroups per CU
+  double* const Pt = XA;
+  double* const Qt = XB;
   __shared__ double part[8][CT_TS + 1];
   __shared__ double wk[CT_TS], yv[CT_TS], rvs[CT_TS];
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, bi = w >> 1, bj = w & 1;
@@ -300,10 +310,10 @@ __global__ __launch_bounds__(256) void k_chol_level(CholLevelArgs a, int task0, 
     // the first source rides in the task record (one dependent load less on the critical path)
     FwdSrc s{t.ai0, t.aj0, t.k0};
     if (q) { s = a.src[t.src0 + q]; __syncthreads(); }   // previous source fully consumed
-    ct_t2 vt, va, vb, vl;
+    ct_t2 va, vb, vl;
     double wv = 0.0;
     if (q == 0) {
-      vt = ct_gld(a.A + (int64_t)t.tgt * CT_TT, tid);
+      acc = ct_gload_frag(a.A + (int64_t)t.tgt * CT_TT, bi, bj, lane);   // the target goes straight into the accumulator layout
       if (diag && tid < CT_TS) rv = a.rhs[t.col * CT_TS + tid];
     }
     if (t.nsrc) {
@@ -312,7 +322,6 @@ __global__ __launch_bounds__(256) void k_chol_level(CholLevelArgs a, int task0, 
       vl = ct_gld(a.Linv + (int64_t)s.k * CT_TT, tid);
       if (diag && tid < CT_TS) wv = a.Wv[s.k * CT_TS + tid];
     }
-    if (q == 0) ct_lst(Qt, tid, vt);
     if (t.nsrc == 0) break;
     ct_lst(XA, tid, va);
     if (!diag) ct_lst(XB, tid, vb);
@@ -320,7 +329,6 @@ __global__ __launch_bounds__(256) void k_chol_level(CholLevelArgs a, int task0, 
     if (diag && tid < CT_TS) wk[tid] = wv;
     __syncthreads();
     CT_STAMP(1);
-    if (q == 0) acc = ct_load_frag(Qt, bi, bj, lane);
     const ct_d4 p = ct_mma_abt<false>(XA, LI, bi, bj, lane, zero);
     ct_d4 qq = zero;
     if (!diag) qq = ct_mma_abt<false>(XB, LI, bi, bj, lane, zero);
@@ -343,7 +351,6 @@ __global__ __launch_bounds__(256) void k_chol_level(CholLevelArgs a, int task0, 
       rv -= ssum;
     }
   }
-  if (t.nsrc == 0) { __syncthreads(); acc = ct_load_frag(Qt, bi, bj, lane); }
   __syncthreads();                     // Pt/Qt no longer read as operands
   CT_STAMP(2);
 

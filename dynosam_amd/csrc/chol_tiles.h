@@ -122,6 +122,11 @@ __device__ __forceinline__ ct_d4 ct_gload_frag(const double* __restrict__ G, int
   for (int r = 0; r < 4; ++r) acc[r] = G[16 * bi + lr + 4 * r + CT_TS * (16 * bj + lc)];
   return acc;
 }
+__device__ __forceinline__ void ct_gstore_frag(double* __restrict__ G, int bi, int bj, int lane, ct_d4 acc) {
+  const int lr = lane >> 4, lc = lane & 15;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) G[16 * bi + lr + 4 * r + CT_TS * (16 * bj + lc)] = acc[r];
+}
 __device__ __forceinline__ ct_d4 ct_load_frag(const double* __restrict__ T, int bi, int bj, int lane) {
   const int lr = lane >> 4, lc = lane & 15;
   ct_d4 acc;
@@ -303,6 +308,34 @@ __global__ __launch_bounds__(256) void k_chol_level(CholLevelArgs a, int task0, 
   const bool dbg_on = a.dbg && blockIdx.x == 0 && tid == 0 && (t.kind & FK_FINAL);
   CT_STAMP(0);
 
+  if (t.kind & FK_ROW) {
+    // two off-diagonal targets (I, I1), (I, I2) of one tile row and one source column K: P = A(I,K) Linv_K^T is formed once
+    const ct_t2 va = ct_gld(a.A + (int64_t)t.ai0 * CT_TT, tid), vb = ct_gld(a.A + (int64_t)t.aj0 * CT_TT, tid),
+                vl = ct_gld(a.Linv + (int64_t)t.k0 * CT_TT, tid), vb2 = ct_gld(a.A + (int64_t)t.src0 * CT_TT, tid);
+    ct_d4 acc1 = ct_gload_frag(a.A + (int64_t)t.tgt * CT_TT, bi, bj, lane), acc2 = ct_gload_frag(a.A + (int64_t)t.col * CT_TT, bi, bj, lane);
+    ct_lst(XA, tid, va);
+    ct_lst(XB, tid, vb);
+    ct_lst(LI, tid, vl);
+    __syncthreads();
+    const ct_d4 p = ct_mma_abt<false>(XA, LI, bi, bj, lane, zero);
+    ct_d4 qq = ct_mma_abt<false>(XB, LI, bi, bj, lane, zero);
+    __syncthreads();
+    ct_store_frag(Pt, bi, bj, lane, p);
+    ct_store_frag(Qt, bi, bj, lane, qq);
+    __syncthreads();
+    acc1 = ct_mma_abt<true>(Pt, Qt, bi, bj, lane, acc1);
+    ct_gstore_frag(a.A + (int64_t)t.tgt * CT_TT, bi, bj, lane, acc1);
+    __syncthreads();                   // Q1 consumed
+    ct_lst(XB, tid, vb2);
+    __syncthreads();
+    qq = ct_mma_abt<false>(XB, LI, bi, bj, lane, zero);
+    __syncthreads();
+    ct_store_frag(Qt, bi, bj, lane, qq);
+    __syncthreads();
+    acc2 = ct_mma_abt<true>(Pt, Qt, bi, bj, lane, acc2);
+    ct_gstore_frag(a.A + (int64_t)t.col * CT_TT, bi, bj, lane, acc2);
+    return;
+  }
   const bool diag = (t.kind & FK_DIAG) != 0;
   double rv = 0.0;
   ct_d4 acc = zero;

@@ -75,7 +75,7 @@ struct BwdLaunch {
   int32_t group0, n_group;   // group g solves the columns bcol[BWD_MAXCOL*(group0+g) ...]
   int32_t push0, n_push;
 };
-enum { FK_DIAG = 1, FK_FINAL = 2 };
+enum { FK_DIAG = 1, FK_FINAL = 2, FK_ROW = 4 };   // FK_ROW: two off-diagonal targets of one tile row: tgt/aj0 and col(=tgt2)/src0(=aj2) share ai0, k0
 struct PanelTask { int32_t tile, k; };   // off-diagonal tile (I,K) of an eliminated column: M(I,K) = A(I,K) Linv_K^T Linv_K
 
 struct TileSym {
@@ -87,6 +87,7 @@ struct TileSym {
   std::vector<FwdTask> ftask;
   std::vector<FwdSrc> fsrc;
   std::vector<int32_t> flaunch;   // [n_flaunch+1] task ranges; launch 0 = leaf factorisations, launch l+1 = level l
+  bool row_pairs = true;            // pair off-diagonal update tasks of one tile row (see build_phase)
   std::vector<PanelTask> panel;     // every off-diagonal tile of the eliminated columns, one launch after the factorisation
   std::vector<BwdCol> bcol;
   std::vector<BwdPush> bpush;
@@ -217,6 +218,28 @@ struct TileSym {
         flops_factor += (double)src.size() * ((o.first <= 1) ? 4 * T3 : 6 * T3);
         fsrc.insert(fsrc.end(), src.begin(), src.end());
         ftask.push_back(t);
+      }
+      // Fewer, fatter workgroups (the dispatcher paces wide levels at ~5 ns per workgroup): two single-source off-diagonal
+      // targets of the same tile row I and source column K become ONE task - they share the product A(I,K) Linv_K^T.
+      if (row_pairs && ftask.size() - (size_t)flaunch.back() > 300) {   // only where the dispatcher is the bottleneck: a pair runs ~1.5x longer
+        const size_t t0 = (size_t)flaunch.back();
+        std::map<std::pair<int32_t, int32_t>, size_t> open;   // (ai, k) -> index of a task waiting for a partner
+        std::vector<char> drop(ftask.size() - t0, 0);
+        for (size_t i = t0; i < ftask.size(); ++i) {
+          FwdTask& t = ftask[i];
+          if (t.kind != 0 || t.nsrc != 1) continue;
+          auto key = std::make_pair(t.ai0, t.k0);
+          auto it = open.find(key);
+          if (it == open.end()) { open[key] = i; continue; }
+          FwdTask& f = ftask[it->second];
+          f.kind |= FK_ROW; f.col = t.tgt; f.src0 = t.aj0;
+          drop[i - t0] = 1;
+          open.erase(it);
+          flops_factor -= 2 * T3;
+        }
+        size_t w = t0;
+        for (size_t i = t0; i < ftask.size(); ++i) if (!drop[i - t0]) ftask[w++] = ftask[i];
+        ftask.resize(w);
       }
       flaunch.push_back((int32_t)ftask.size());
     }

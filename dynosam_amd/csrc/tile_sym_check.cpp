@@ -103,6 +103,21 @@ int main(int argc, char** argv) {
     for (int32_t id : ids) {
       const FwdTask& t = sym.ftask[id];
 
+      if (t.kind & FK_ROW) {   // two targets of one tile row sharing P = A(ai0) Linv^T
+        mul_abt(&A[(size_t)t.ai0 * TT], &Li[(size_t)t.k0 * TT], P.data());
+        const int32_t tg[2] = {t.tgt, t.col}, aj[2] = {t.aj0, t.src0};
+        for (int g = 0; g < 2; ++g) {
+          mul_abt(&A[(size_t)aj[g] * TT], &Li[(size_t)t.k0 * TT], Q.data());
+          double* Tg = &A[(size_t)tg[g] * TT];
+          for (int i = 0; i < TS; ++i)
+            for (int j = 0; j < TS; ++j) {
+              double acc = 0;
+              for (int k = 0; k < TS; ++k) acc += P[i + TS * k] * Q[j + TS * k];
+              Tg[i + TS * j] -= acc;
+            }
+        }
+        continue;
+      }
       double* T = &A[(size_t)t.tgt * TT];
       for (int32_t q = t.src0; q < t.src0 + t.nsrc; ++q) {
         const FwdSrc& sc = sym.fsrc[q];

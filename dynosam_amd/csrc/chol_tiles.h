@@ -309,10 +309,14 @@ __global__ __launch_bounds__(256) void k_chol_level(CholLevelArgs a, int task0, 
   CT_STAMP(0);
 
   if (t.kind & FK_ROW) {
-    // two off-diagonal targets (I, I1), (I, I2) of one tile row and one source column K: P = A(I,K) Linv_K^T is formed once
-    const ct_t2 va = ct_gld(a.A + (int64_t)t.ai0 * CT_TT, tid), vb = ct_gld(a.A + (int64_t)t.aj0 * CT_TT, tid),
-                vl = ct_gld(a.Linv + (int64_t)t.k0 * CT_TT, tid), vb2 = ct_gld(a.A + (int64_t)t.src0 * CT_TT, tid);
-    ct_d4 acc1 = ct_gload_frag(a.A + (int64_t)t.tgt * CT_TT, bi, bj, lane), acc2 = ct_gload_frag(a.A + (int64_t)t.col * CT_TT, bi, bj, lane);
+    // up to FWD_ROW_MAX off-diagonal targets (I, I_j) of one tile row and one source column K: P = A(I,K) Linv_K^T is formed
+    // once; the column operand and the target of item j + 1 are fetched while item j is computed
+    const int n = t.nsrc;
+    const ct_t2 va = ct_gld(a.A + (int64_t)t.ai0 * CT_TT, tid), vb = ct_gld(a.A + (int64_t)t.aj0 * CT_TT, tid), vl = ct_gld(a.Linv + (int64_t)t.k0 * CT_TT, tid);
+    ct_d4 acc = ct_gload_frag(a.A + (int64_t)t.tgt * CT_TT, bi, bj, lane), accn = zero;
+    FwdSrc nx = a.src[t.src0 + 1];
+    ct_t2 vbn = ct_gld(a.A + (int64_t)nx.aj * CT_TT, tid);
+    accn = ct_gload_frag(a.A + (int64_t)nx.ai * CT_TT, bi, bj, lane);
     ct_lst(XA, tid, va);
     ct_lst(XB, tid, vb);
     ct_lst(LI, tid, vl);
@@ -323,17 +327,26 @@ __global__ __launch_bounds__(256) void k_chol_level(CholLevelArgs a, int task0, 
     ct_store_frag(Pt, bi, bj, lane, p);
     ct_store_frag(Qt, bi, bj, lane, qq);
     __syncthreads();
-    acc1 = ct_mma_abt<true>(Pt, Qt, bi, bj, lane, acc1);
-    ct_gstore_frag(a.A + (int64_t)t.tgt * CT_TT, bi, bj, lane, acc1);
-    __syncthreads();                   // Q1 consumed
-    ct_lst(XB, tid, vb2);
-    __syncthreads();
-    qq = ct_mma_abt<false>(XB, LI, bi, bj, lane, zero);
-    __syncthreads();
-    ct_store_frag(Qt, bi, bj, lane, qq);
-    __syncthreads();
-    acc2 = ct_mma_abt<true>(Pt, Qt, bi, bj, lane, acc2);
-    ct_gstore_frag(a.A + (int64_t)t.col * CT_TT, bi, bj, lane, acc2);
+    int cur = t.tgt;
+    for (int i = 0;; ++i) {
+      acc = ct_mma_abt<true>(Pt, Qt, bi, bj, lane, acc);
+      ct_gstore_frag(a.A + (int64_t)cur * CT_TT, bi, bj, lane, acc);
+      if (i + 1 >= n) break;
+      __syncthreads();                   // Q of this item consumed
+      ct_lst(XB, tid, vbn);
+      acc = accn;
+      cur = nx.ai;
+      if (i + 2 < n) {
+        nx = a.src[t.src0 + i + 2];
+        vbn = ct_gld(a.A + (int64_t)nx.aj * CT_TT, tid);
+        accn = ct_gload_frag(a.A + (int64_t)nx.ai * CT_TT, bi, bj, lane);
+      }
+      __syncthreads();
+      qq = ct_mma_abt<false>(XB, LI, bi, bj, lane, zero);
+      __syncthreads();
+      ct_store_frag(Qt, bi, bj, lane, qq);
+      __syncthreads();
+    }
     return;
   }
   const bool diag = (t.kind & FK_DIAG) != 0;

@@ -75,7 +75,8 @@ struct BwdLaunch {
   int32_t group0, n_group;   // group g solves the columns bcol[BWD_MAXCOL*(group0+g) ...]
   int32_t push0, n_push;
 };
-enum { FK_DIAG = 1, FK_FINAL = 2, FK_ROW = 4 };   // FK_ROW: two off-diagonal targets of one tile row: tgt/aj0 and col(=tgt2)/src0(=aj2) share ai0, k0
+enum { FK_DIAG = 1, FK_FINAL = 2, FK_ROW = 4 };   // FK_ROW: nsrc off-diagonal targets of ONE tile row and source column (ai0, k0 shared): items fsrc[src0 + j] = {ai: target tile, aj: column operand tile}; item 0 is also in tgt / aj0
+constexpr int FWD_ROW_MAX = 4;   // targets per row task
 struct PanelTask { int32_t tile, k; };   // off-diagonal tile (I,K) of an eliminated column: M(I,K) = A(I,K) Linv_K^T Linv_K
 
 struct TileSym {
@@ -87,6 +88,7 @@ struct TileSym {
   std::vector<FwdTask> ftask;
   std::vector<FwdSrc> fsrc;
   std::vector<int32_t> flaunch;   // [n_flaunch+1] task ranges; launch 0 = leaf factorisations, launch l+1 = level l
+  int row_min_tasks = 300;          // levels with more tasks than this use row tasks
   bool row_pairs = true;            // pair off-diagonal update tasks of one tile row (see build_phase)
   std::vector<PanelTask> panel;     // every off-diagonal tile of the eliminated columns, one launch after the factorisation
   std::vector<BwdCol> bcol;
@@ -219,23 +221,27 @@ struct TileSym {
         fsrc.insert(fsrc.end(), src.begin(), src.end());
         ftask.push_back(t);
       }
-      // Fewer, fatter workgroups (the dispatcher paces wide levels at ~5 ns per workgroup): two single-source off-diagonal
-      // targets of the same tile row I and source column K become ONE task - they share the product A(I,K) Linv_K^T.
-      if (row_pairs && ftask.size() - (size_t)flaunch.back() > 300) {   // only where the dispatcher is the bottleneck: a pair runs ~1.5x longer
+      // Fewer, fatter workgroups in wide levels (a level costs ~7 us + 5 ns per workgroup): up to FWD_ROW_MAX single-source
+      // off-diagonal targets of the same tile row I and source column K become ONE task - the product A(I,K) Linv_K^T is
+      // formed once and the column operands of the following targets are prefetched while the current one is computed.
+      if (row_pairs && (int)(ftask.size() - (size_t)flaunch.back()) > row_min_tasks) {
         const size_t t0 = (size_t)flaunch.back();
-        std::map<std::pair<int32_t, int32_t>, size_t> open;   // (ai, k) -> index of a task waiting for a partner
+        std::map<std::pair<int32_t, int32_t>, std::vector<size_t>> rows;   // (ai, k) -> tasks
+        for (size_t i = t0; i < ftask.size(); ++i)
+          if (ftask[i].kind == 0 && ftask[i].nsrc == 1) rows[{ftask[i].ai0, ftask[i].k0}].push_back(i);
         std::vector<char> drop(ftask.size() - t0, 0);
-        for (size_t i = t0; i < ftask.size(); ++i) {
-          FwdTask& t = ftask[i];
-          if (t.kind != 0 || t.nsrc != 1) continue;
-          auto key = std::make_pair(t.ai0, t.k0);
-          auto it = open.find(key);
-          if (it == open.end()) { open[key] = i; continue; }
-          FwdTask& f = ftask[it->second];
-          f.kind |= FK_ROW; f.col = t.tgt; f.src0 = t.aj0;
-          drop[i - t0] = 1;
-          open.erase(it);
-          flops_factor -= 2 * T3;
+        for (auto& rw : rows) {
+          const auto& ids = rw.second;
+          for (size_t c0 = 0; c0 + 1 < ids.size(); c0 += FWD_ROW_MAX) {
+            const size_t c1 = std::min(ids.size(), c0 + FWD_ROW_MAX);
+            if (c1 - c0 < 2) break;
+            FwdTask& f = ftask[ids[c0]];
+            f.kind |= FK_ROW; f.src0 = (int32_t)fsrc.size(); f.nsrc = (int32_t)(c1 - c0);
+            for (size_t c = c0; c < c1; ++c) {
+              fsrc.push_back({ftask[ids[c]].tgt, ftask[ids[c]].aj0, f.k0});
+              if (c > c0) { drop[ids[c] - t0] = 1; flops_factor -= 2 * T3; }
+            }
+          }
         }
         size_t w = t0;
         for (size_t i = t0; i < ftask.size(); ++i) if (!drop[i - t0]) ftask[w++] = ftask[i];

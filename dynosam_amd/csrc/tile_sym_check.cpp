@@ -81,6 +81,7 @@ int main(int argc, char** argv) {
     g[i] = !is_pad[i] ? U(rng) : 0.0;
   }
   TileSym sym;
+  if (getenv("TS_ROW_MIN")) sym.row_min_tasks = atoi(getenv("TS_ROW_MIN"));   // force row tasks in narrow levels too
   const int nel = getenv("TS_NELIM") ? atoi(getenv("TS_NELIM")) : -1;   // two-phase schedule: must still solve the whole system
   sym.analyse(nt, lower, true, nel < 0 ? -1 : std::min(nel, nt), nel >= 0);
   // tile buffers
@@ -103,12 +104,13 @@ int main(int argc, char** argv) {
     for (int32_t id : ids) {
       const FwdTask& t = sym.ftask[id];
 
-      if (t.kind & FK_ROW) {   // two targets of one tile row sharing P = A(ai0) Linv^T
+      if (t.kind & FK_ROW) {   // several targets of one tile row sharing P = A(ai0) Linv^T
         mul_abt(&A[(size_t)t.ai0 * TT], &Li[(size_t)t.k0 * TT], P.data());
-        const int32_t tg[2] = {t.tgt, t.col}, aj[2] = {t.aj0, t.src0};
-        for (int g = 0; g < 2; ++g) {
-          mul_abt(&A[(size_t)aj[g] * TT], &Li[(size_t)t.k0 * TT], Q.data());
-          double* Tg = &A[(size_t)tg[g] * TT];
+        if (sym.fsrc[t.src0].ai != t.tgt || sym.fsrc[t.src0].aj != t.aj0 || t.nsrc < 2 || t.nsrc > FWD_ROW_MAX) { printf("FAIL: malformed row task\n"); return 1; }
+        for (int g = 0; g < t.nsrc; ++g) {
+          const FwdSrc& it = sym.fsrc[t.src0 + g];
+          mul_abt(&A[(size_t)it.aj * TT], &Li[(size_t)t.k0 * TT], Q.data());
+          double* Tg = &A[(size_t)it.ai * TT];
           for (int i = 0; i < TS; ++i)
             for (int j = 0; j < TS; ++j) {
               double acc = 0;

@@ -37,3 +37,14 @@ def test_twisted_order_halves_the_dependent_launches(checker):
     assert band["levels"] == band["nt"]       # a band in frame order is one chain
     assert twisted["levels"] < 0.56 * band["levels"]
     assert twisted["residual"] < 1e-10 and band["residual"] < 1e-10
+
+
+def test_row_tasks_solve_the_system(checker):
+    """levels whose off-diagonal updates are packed into row tasks (several targets per workgroup) - forced for every level"""
+    for args in ((200, 14, 1, 2), (1200, 84, 1, 7, 0, 560), (120, 8, 1, 6, 5)):
+        out = subprocess.run([checker, *map(str, args)], capture_output=True, text=True, timeout=300, env=dict(os.environ, TS_ROW_MIN="0"))
+        assert out.returncode == 0, out.stdout + out.stderr
+        kv = dict(tok.split("=") for tok in out.stdout.split() if "=" in tok)
+        assert float(kv["residual"]) < 1e-10
+        plain = run(checker, *args)
+        assert float(kv["fwd_tasks"]) < 0.9 * plain["fwd_tasks"]       # and they really are fewer, fatter tasks (0.4x on the wide band)

@@ -247,6 +247,14 @@ struct TileSym {
         for (size_t i = t0; i < ftask.size(); ++i) if (!drop[i - t0]) ftask[w++] = ftask[i];
         ftask.resize(w);
       }
+      {
+        // longest first behind the finalising tasks: a level has more workgroups than the chip has slots, so the ones
+        // dispatched last should be the short ones (contractions: 3 per source; a row task 1 + 2 per target)
+        auto cost = [](const FwdTask& f) { return (f.kind & FK_ROW) ? 1 + 2 * f.nsrc : 3 * std::max(1, f.nsrc); };
+        auto first = ftask.begin() + flaunch.back();
+        while (first != ftask.end() && (first->kind & FK_FINAL)) ++first;
+        std::stable_sort(first, ftask.end(), [&](const FwdTask& x, const FwdTask& y) { return cost(x) > cost(y); });
+      }
       flaunch.push_back((int32_t)ftask.size());
     }
   }

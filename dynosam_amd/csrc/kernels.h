@@ -871,28 +871,70 @@ __global__ __launch_bounds__(256) void k_assemble_chunks(AssembleView A, const d
   const bool act = ij < 6;
   d4_t acc = {0.0, 0.0, 0.0, 0.0};
   if (A.ch_kind[ch] == 0) {
+    // TWO contributions per MFMA: operand rows 0..5 carry contribution 2m, rows 8..13 contribution 2m + 1, so the two 6x6
+    // products land in the diagonal blocks (0..5, 0..5) and (8..13, 8..13) of the 16x16 accumulator (the off-diagonal blocks
+    // are never read) and are added at the end: half the loads and half the MFMAs of one contribution per instruction -
+    // the kernel is bound by the number of vector-memory instructions, not by bytes or flops.
     int e1 = 0, e2 = 0;
     if (lane < n) { e1 = A.sp_e[2 * (lo + lane)]; e2 = A.sp_e[2 * (lo + lane) + 1]; }
-    const bool ld = act && g < 3;
-    const int zo = ld ? 3 * ij + g : 0;
-    // 4 contributions per trip: their loads are independent and issue back to back
-    for (int k0 = 0; k0 < n; k0 += 4) {
+    const int half = ij >> 3, r6 = ij & 7;
+    const bool ld = r6 < 6 && g < 3;
+    const int zo = ld ? 3 * r6 + g : 0;
+    // 4 MFMAs (8 contributions) per trip: their loads are independent and issue back to back
+    for (int k0 = 0; k0 < n; k0 += 8) {
       double a[4], b[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int k = k0 + u;   // lanes >= n hold row 0 (a valid address); masked below
-        const int f1 = __builtin_amdgcn_readlane(e1, k & 63), f2 = __builtin_amdgcn_readlane(e2, k & 63);
+        const int ka = k0 + 2 * u;   // lanes >= n hold row 0 (a valid address); masked below
+        const int f1a = __builtin_amdgcn_readlane(e1, ka & 63), f2a = __builtin_amdgcn_readlane(e2, ka & 63);
+        const int f1b = __builtin_amdgcn_readlane(e1, (ka + 1) & 63), f2b = __builtin_amdgcn_readlane(e2, (ka + 1) & 63);
+        const int f1 = half ? f1b : f1a, f2 = half ? f2b : f2a;
         a[u] = 0.0; b[u] = 0.0;
-        if (ld && k < n) { a[u] = -Z[18 * (int64_t)f1 + zo]; b[u] = Z[18 * (int64_t)f2 + zo]; }
+        if (ld && ka + half < n) { a[u] = -Z[18 * (int64_t)f1 + zo]; b[u] = Z[18 * (int64_t)f2 + zo]; }
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
     }
+    // lane (j, g) holds rows g + 4 r of column j: block one = r 0,1 of columns 0..5, block two = r 2,3 of columns 8..13
+    acc[0] += __shfl_down(acc[2], 8, 16);
+    acc[1] += __shfl_down(acc[3], 8, 16);
   } else {
     int64_t oa = 0, ob = 0;
     int d = 0, wv = 0x66;
     if (lane < n) { oa = A.dp_a[lo + lane]; ob = A.dp_b[lo + lane]; d = A.dp_d[lo + lane]; wv = A.dp_w[lo + lane]; }
     double pacc0 = 0.0, pacc1 = 0.0;   // constant blocks of the dense prior, in the accumulator's layout
+    const bool has_prior = __ballot(lane < n && d < 0) != 0ull;
+    if (!has_prior) {
+      // 4 contributions per trip: every lane issues its (up to 4 x 4) loads unconditionally - idle lanes read the first
+      // element of the block and are zeroed by a select - so that the trips' loads are in flight together; the loop below
+      // (one contribution at a time, loads under conditions) costs a memory round trip per contribution: a chunk of 64
+      // direct contributions took ~100 us and set the duration of the whole kernel.
+      d4_t acc1 = {0.0, 0.0, 0.0, 0.0};
+      for (int k0 = 0; k0 < n; k0 += 4) {
+        double a0[4], b0[4], a1[4], b1[4];
+        int dq[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int k = min(k0 + u, n - 1);
+          const int64_t pa = ((int64_t)__builtin_amdgcn_readlane((int)(oa >> 32), k) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)oa, k);
+          const int64_t pb = ((int64_t)__builtin_amdgcn_readlane((int)(ob >> 32), k) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)ob, k);
+          const int dd = k0 + u < n ? __builtin_amdgcn_readlane(d, k) : 0;
+          const int ww = __builtin_amdgcn_readlane(wv, k), wa = ww & 15, wb = ww >> 4;
+          const bool r0 = act && g < dd, r1 = act && 4 + g < dd;
+          const bool ma0 = r0 && ij < wa, mb0 = r0 && ij < wb, ma1 = r1 && ij < wa, mb1 = r1 && ij < wb;
+          const double va0 = Jbuf[pa + (ma0 ? wa * g + ij : 0)], vb0 = Jbuf[pb + (mb0 ? wb * g + ij : 0)];
+          const double va1 = Jbuf[pa + (ma1 ? wa * (4 + g) + ij : 0)], vb1 = Jbuf[pb + (mb1 ? wb * (4 + g) + ij : 0)];
+          a0[u] = ma0 ? va0 : 0.0; b0[u] = mb0 ? vb0 : 0.0; a1[u] = ma1 ? va1 : 0.0; b1[u] = mb1 ? vb1 : 0.0;
+          dq[u] = dd;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (dq[u] > 0) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b0[u], acc, 0, 0, 0);
+          if (dq[u] > 4) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b1[u], acc1, 0, 0, 0);
+        }
+      }
+      acc += acc1;
+    } else
 #pragma unroll 2
     for (int k = 0; k < n; ++k) {
       const int64_t pa = ((int64_t)__builtin_amdgcn_readlane((int)(oa >> 32), k) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)oa, k);

@@ -4,7 +4,7 @@ from dynosam_amd import synth
 from dynosam_amd.optimizer import Context, LevenbergMarquardtParams
 g = synth.make_hybrid_graph(synth.config(2))
 ctx = Context(); ctx.upload(g)
-P = LevenbergMarquardtParams(); P.max_iterations = 6; P.relative_error_tol = 1e-300; P.absolute_error_tol = 0.0
+P = LevenbergMarquardtParams(); P.max_iterations = int(os.environ.get("ITERS", "6")); P.relative_error_tol = 1e-300; P.absolute_error_tol = 0.0
 ctx.optimize(P)
 ctx.set_values(g.var_state)
 P.verbosity = 2

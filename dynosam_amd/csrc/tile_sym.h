@@ -188,7 +188,7 @@ struct TileSym {
     for (int J = lo; J < hi; ++J) by_level[lv[J]].push_back(J);
     // pre-launch: columns of the phase that receive no update inside it
     if (maxl >= 0)
-      for (int J : by_level[0]) { ftask.push_back({diag(J), 0, 0, FK_DIAG | FK_FINAL, J, 0, 0, 0}); flops_factor += 3 * T3; }
+      for (int J : by_level[0]) { ftask.push_back({diag(J), 0, 0, FK_DIAG | FK_FINAL, J, 0, 0, 0}); flops_factor += 5 * T3; }
     flaunch.push_back((int32_t)ftask.size());
     for (int l = 0; l <= maxl; ++l) {
       std::map<int32_t, std::vector<FwdSrc>> groups;   // target tile id -> sources (ordered by K: deterministic)
@@ -216,8 +216,8 @@ struct TileSym {
         const int I = row_idx[src.front().ai];
         FwdTask t{o.second, (int32_t)fsrc.size(), (int32_t)src.size(), 0, -1, src.front().ai, src.front().aj, src.front().k};
         if (o.first <= 1) { t.kind |= FK_DIAG; t.col = I; }
-        if (o.first == 0) { t.kind |= FK_FINAL; flops_factor += 3 * T3; }
-        flops_factor += (double)src.size() * ((o.first <= 1) ? 4 * T3 : 6 * T3);
+        if (o.first == 0) { t.kind |= FK_FINAL; flops_factor += 5 * T3; }   // tall potrf + T^-1 = Linv^T Linv
+        flops_factor += (double)src.size() * 4 * T3;   // two contractions per source: P, then P P^T (diagonal) or P' = A T^-1, then P' A'^T
         fsrc.insert(fsrc.end(), src.begin(), src.end());
         ftask.push_back(t);
       }

@@ -201,7 +201,7 @@ def pmc_traffic(kernel):
     return None
 
 
-def frontend_bench(device, cpu=True, frames=50):
+def frontend_bench(device, cpu=True, frames=200):
     """BASELINE.json's second metric: frontend frames/sec on 640x480 RGB-D (config 4).  One "frame" = dense flow
     k -> k+1 (pyramid, descriptors, MFMA correlation volume + arg-max, refinement) + propagation of 1000
     dynamic features, images already resident in HBM (upload outside the timed region)."""
@@ -219,8 +219,9 @@ def frontend_bench(device, cpu=True, frames=50):
     zeros = np.zeros(1000, np.int64)
     flow, _ = t.dense_flow()
     e = np.linalg.norm(flow - sc["flow_gt"], axis=-1)[sc["valid"]]
-    for _ in range(3):
+    for _ in range(5):                      # untimed warm-up of the whole per-frame path (first calls allocate the point buffers)
         t.dense_flow(download=False)
+        t.track_dynamic(kp, prev, zeros, zeros)
     stages = dict(ms_gray_pyramid=0.0, ms_descriptors=0.0, ms_correlation=0.0, ms_refine=0.0, ms_track=0.0)
     t0 = time.perf_counter()
     for _ in range(frames):

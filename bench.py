@@ -295,20 +295,24 @@ def window_bench(device, frames=55):
     from dynosam_amd import synth, sliding_window as SW
     from dynosam_amd.optimizer import Context
     g = synth.make_hybrid_graph(synth.config(2, frames=frames, static_points=40 * frames, dynamic_points_per_object=2 * frames))
-    sw = SW.SlidingWindowOptimization(window_size=20, overlap=4, ctx=Context(device=device))
-    rows = []
-    for k, blocks, vals in SW.frame_stream(g):
-        t0 = time.perf_counter()
-        r = sw.update(blocks, vals, k)
-        if r.optimized:
-            rows.append(dict(frame=k, factors=r.graph.n_factors, update_ms=1e3 * (time.perf_counter() - t0), lm_ms=1e3 * r.report.solve_seconds,
-                             iterations=int(r.report.iterations), inner=int(r.report.inner_iterations), separator_poses=len(r.prior.keys),
-                             containers=sum(len(b.slot) for b in r.prior_blocks)))
-    sw.ctx.close()
+    ctx = Context(device=device)
+    # pass 0 (untimed) lets the context's device buffers grow to the size of this stream, as in a long-running backend
+    # (a re-allocation costs ~10-20 ms in front of the next kernel); pass 1 is the measurement
+    for rep in range(2):
+        sw = SW.SlidingWindowOptimization(window_size=20, overlap=4, ctx=ctx)
+        rows = []
+        for k, blocks, vals in SW.frame_stream(g):
+            t0 = time.perf_counter()
+            r = sw.update(blocks, vals, k)
+            if r.optimized:
+                rows.append(dict(frame=k, factors=r.graph.n_factors, update_ms=1e3 * (time.perf_counter() - t0), lm_ms=1e3 * r.report.solve_seconds,
+                                 iterations=int(r.report.iterations), inner=int(r.report.inner_iterations), separator_poses=len(r.prior.keys),
+                                 containers=sum(len(b.slot) for b in r.prior_blocks)))
+    ctx.close()
     return {"metric": "sliding-window solve (20 keyframes, overlap 4)", "windows": rows,
             "lm_ms_mean": float(np.mean([r["lm_ms"] for r in rows])), "update_ms_mean": float(np.mean([r["update_ms"] for r in rows])),
             "budget_ms_30hz": 33.3, "note": "update_ms = flatten + upload + LM + value download + marginalisation of one window; "
-            "it fires once per (window - overlap) = 16 frames"}
+            "it fires once per (window - overlap) = 16 frames; second pass over the stream with the same context (buffers already grown)"}
 
 
 def cpu_baseline(g, base_factors):

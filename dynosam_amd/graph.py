@@ -269,4 +269,9 @@ class FlatGraph:
             owner_frame = np.where(has_pt, pt_first, pose_first)
             owner = np.minimum(world_size - 1, (owner_frame - fmin) * world_size // span)   # == the library's rank_of(frame)
             out.append(b.subset(owner == rank))
-        return FlatGraph(self.var_keys, self.var_type, self.var_state, out, dict(self.meta))
+        g = FlatGraph(self.var_keys, self.var_type, self.var_state, out, dict(self.meta))
+        # the dense marginal prior is ONE factor: it lives on rank 0 (never dropped silently; a library build that cannot
+        # shard a prior rejects the upload)
+        if getattr(self, "prior", None) is not None and rank == 0:
+            g.prior = self.prior
+        return g

@@ -129,10 +129,15 @@ class SlidingWindowOptimization:
         retained = {k: v for k, v in result.items() if self.is_recent(k)}
         to_marg = [k for k in result if k not in retained]
         t4 = time.perf_counter()
-        lin_blocks, prior = self.ctx.marginalize(to_marg)
+        if to_marg:
+            lin_blocks, prior = self.ctx.marginalize(to_marg)
+            self.prior_blocks = [keyed(b, g.var_keys) for b in lin_blocks]
+            self.prior = prior
+        else:
+            # "There are no keys to marginalize. Simply return the input factors" (SlidingWindowOptimization.cc:176-178): the
+            # NONLINEAR graph of this window (with the priors it already carried) is the next window's prior, not re-wrapped
+            self.prior_blocks = blocks
         t5 = time.perf_counter()
-        self.prior_blocks = [keyed(b, g.var_keys) for b in lin_blocks]
-        self.prior = prior
         self.marginalized.update(to_marg)
         self.frame_window = self.frame_window[-self.overlap:] if self.overlap else []
         self.blocks = []

@@ -23,7 +23,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import symbols as S
-from .graph import (F_BETWEEN_POSE3, F_HYBRID_MOTION, F_HYBRID_SMOOTHING, F_POSE_TO_POINT, F_PRIOR_POSE3,
+from .graph import (F_BETWEEN_POSE3, F_HYBRID_MOTION, F_HYBRID_SMOOTHING, F_POSE_TO_POINT, F_PRIOR_POSE3, F_STEREO_POINT,
                     VAR_POINT3, VAR_POSE3, FactorBlock, FlatGraph)
 
 # ------------------------------------------------------------------------------------------
@@ -548,3 +548,37 @@ def make_wcpe_graph(cfg: ScenarioConfig) -> FlatGraph:
     s0 += len(sm)
     blocks.append(FactorBlock(F_PRIOR_POSE3, np.arange(s0, s0 + J), Lvar[:, :1], Lgt.reshape(J, K, 12)[:, 0], iso6(0.1, 0.1, J)))
     return FlatGraph(keys[order], vtype[order], state[order], blocks, dict(cfg=cfg, gt_state=gt[order], frames=K, objects=J))
+
+
+def to_stereo_static(g: FlatGraph, fx: float = 718.856, fy: float = 718.856, u0: float = 607.19, v0: float = 185.2157,
+                     baseline: float = 0.1, sigma_px: float = 1.0, k_huber: float = None, behind: int = 0, seed: int = 0) -> FlatGraph:
+    """The same scenario with `static_formulation_type = 2` (the shipped default, backend.flags:52): every static
+    PoseToPointFactor becomes a gtsam::GenericStereoFactor<Pose3, Point3> on the fake stereo rig of an RGB-D camera
+    (StaticFormulationUpdater::StereoProjection, Formulation-impl.hpp:258-411; RGBDCamera::getFakeStereoCalib /
+    rightKeypoint, dynosam_cv/src/RGBDCamera.cc:79-112): the measured camera-frame point z = (x, y, d) is re-expressed as
+    (uL, uR, v) = (fx x/d + u0, uL - fx b/d, fy y/d + v0), pixel noise sigma_px isotropic, Huber k from the block (or k_huber).
+    `behind` > 0 moves the INITIAL estimate of that many landmarks behind one of their observing cameras, so that the first
+    linearisations take GenericStereoFactor's cheirality branch (error = 2 fx on every row, zero Jacobians)."""
+    rng = np.random.default_rng(seed)
+    blocks = []
+    state = g.var_state.copy()
+    for b in g.blocks:
+        if b.type != F_POSE_TO_POINT:
+            blocks.append(b)
+            continue
+        z = np.asarray(b.meas, dtype=np.float64).reshape(-1, 3)
+        d = z[:, 2]
+        uL = fx * z[:, 0] / d + u0
+        meas = np.stack([uL, uL - fx * baseline / d, fy * z[:, 1] / d + v0], -1)
+        R = np.zeros((len(z), 9))
+        R[:, 0] = R[:, 4] = R[:, 8] = 1.0 / sigma_px
+        hk = b.huber_k if k_huber is None else np.full(len(z), float(k_huber))
+        K = np.tile(np.array([fx, fy, 0.0, u0, v0, baseline]), (len(z), 1))
+        blocks.append(FactorBlock(F_STEREO_POINT, b.slot, b.var_idx, meas, R, hk, K))
+        if behind:
+            pick = rng.choice(len(z), size=min(behind, len(z)), replace=False)
+            for i in pick:
+                xv, lv = int(b.var_idx[i, 0]), int(b.var_idx[i, 1])
+                Rm, t = state[xv, :9].reshape(3, 3), state[xv, 9:12]
+                state[lv, :3] = Rm @ np.array([0.3, -0.2, -1.5]) + t       # 1.5 m behind that camera
+    return FlatGraph(g.var_keys, g.var_type, state, blocks, dict(g.meta))

@@ -57,6 +57,45 @@ class WindowOracle:
             self.prior_var = np.array([g.key_index(int(k)) for k in g.prior.keys])
         else:
             self.prior_var = None
+        # Point3 variables whose 3x3 diagonal block of the normal equations couples with no other point (no dense prior names
+        # them, no factor holds two points): full-density windows solve the SAME damped system through their Schur complement
+        # (see _solve; windows below SCHUR_MIN_DIM keep the plain dense Cholesky)
+        coupled = np.zeros(g.n_vars, bool)
+        if self.prior_var is not None:
+            coupled[self.prior_var] = True
+        for b in g.blocks:
+            vi = np.asarray(b.var_idx).reshape(b.count, -1)
+            is_pt = g.var_type[vi] == 1
+            two = is_pt.sum(axis=1) >= 2
+            coupled[vi[two][is_pt[two]]] = True
+        self.free_pts = np.nonzero((g.var_type == 1) & ~coupled)[0]
+
+    SCHUR_MIN_DIM = 1500
+
+    def _solve(self, H, g, lam):
+        """delta = (H + lam I)^-1 g by Cholesky; raises numpy.linalg.LinAlgError when the damped system is not positive definite
+        (gtsam::IndeterminantLinearSystemException -> "not solved" in tryLambda)"""
+        if self.n < self.SCHUR_MIN_DIM or len(self.free_pts) == 0:
+            Lc = np.linalg.cholesky(H + lam * np.eye(self.n))
+            return np.linalg.solve(Lc.T, np.linalg.solve(Lc, g))
+        L = (self.off[self.free_pts][:, None] + np.arange(3)[None]).reshape(-1)          # eliminated scalars
+        mask = np.ones(self.n, bool); mask[L] = False
+        Pi = np.nonzero(mask)[0]
+        nl = len(self.free_pts)
+        D = H[L.reshape(nl, 3)[:, :, None], L.reshape(nl, 3)[:, None, :]] + lam * np.eye(3)[None]   # [nl, 3, 3]
+        Lc3 = np.linalg.cholesky(D)                                                      # LinAlgError if a point block is not PD
+        Dinv = np.linalg.inv(D)
+        W = H[np.ix_(Pi, L)].reshape(len(Pi), nl, 3)
+        WD = np.einsum("pna,nab->pnb", W, Dinv).reshape(len(Pi), 3 * nl)
+        S = H[np.ix_(Pi, Pi)] + lam * np.eye(len(Pi)) - WD @ W.reshape(len(Pi), 3 * nl).T
+        rhs = g[Pi] - WD @ g[L]
+        Ls = np.linalg.cholesky(S)
+        dp = np.linalg.solve(Ls.T, np.linalg.solve(Ls, rhs))
+        dl = np.einsum("nab,nb->na", Dinv, (g[L] - W.reshape(len(Pi), 3 * nl).T @ dp).reshape(nl, 3)).reshape(-1)
+        delta = np.zeros(self.n)
+        delta[Pi] = dp; delta[L] = dl
+        del Lc3
+        return delta
 
     # ---- every factor as (vars, [A_s], b) at `state`; b = -residual (gtsam::NoiseModelFactor::linearize) ----
     def factors(self, state):
@@ -152,8 +191,7 @@ class WindowOracle:
                 H, g, c0 = self.normal_equations(x)
                 while True:
                     try:
-                        Lc = np.linalg.cholesky(H + lam * np.eye(self.n))
-                        delta = np.linalg.solve(Lc.T, np.linalg.solve(Lc, g))
+                        delta = self._solve(H, g, lam)
                         solved = True
                     except np.linalg.LinAlgError:
                         solved = False

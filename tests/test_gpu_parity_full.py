@@ -1,0 +1,203 @@
+"""Parity on the configurations that carry the claim (BASELINE.json north_star: "final cost within 1e-6 relative of
+reference" on the 100k-factor graph), all through the C-ABI, each against the CPU oracle on the same seeded input:
+
+  config 2   the whole LM solve to GTSAM's default convergence: identical accept / reject trace, identical outer and
+             inner iteration counts, final cost within 1e-6 relative, values within 1e-5
+  config 5   (1.97 M factors) the first three outer iterations, single context AND sharded over in-process ranks
+  config 3   one full-density window (20 keyframes of the config-2 stream, ~9 k factors): the marginal of the first window
+             and the LM of the next one (linear containers + dense prior on poses and points)
+  a2         a stereo-static graph (static_formulation_type = 2) whose first linearisations take GenericStereoFactor's
+             cheirality branch
+  a7         Robust(Huber) on HybridSmoothingFactor blocks (a generic ABI caller may pass it)
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from dynosam_amd import graph as G  # noqa: E402
+from dynosam_amd import synth  # noqa: E402
+
+
+def trace(r):
+    return [bool(r.trace_accepted[i]) for i in range(r.trace_len)]
+
+
+def test_config2_full_convergence_matches_oracle(oracle):
+    from dynosam_amd.optimizer import Context
+    g = synth.make_hybrid_graph(synth.config(2))
+    og = oracle.OracleGraph(g)
+    ro, _ = og.optimize()                      # ~36 outer iterations / ~72 linear solves, ~15-20 s on 8 host cores
+    c = Context(); c.upload(g)
+    r = c.optimize()
+    assert trace(r) == trace(ro)
+    assert r.iterations == ro.iterations and r.inner_iterations == ro.inner_iterations
+    for i in range(ro.trace_len):              # every tentative cost along the way, not only the last one
+        if np.isfinite(ro.trace_error[i]):
+            assert abs(r.trace_error[i] - ro.trace_error[i]) <= 1e-6 * ro.trace_error[i], i
+    assert abs(r.error_after - ro.error_after) <= 1e-6 * ro.error_after
+    assert abs(r.lambda_final - ro.lambda_final) <= 1e-12 * ro.lambda_final
+    v, vo = c.values(), og.state()
+    assert np.abs(v - vo).max() <= 1e-5
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def config5(oracle):
+    from dynosam_amd.optimizer import LevenbergMarquardtParams
+    g = synth.make_hybrid_graph(synth.config(5))
+    P = LevenbergMarquardtParams()
+    P.max_iterations = 3
+    og = oracle.OracleGraph(g)
+    ro, _ = og.optimize(P)                     # ~20 s, 3.4 GB on the host
+    vo = og.state()
+    del og
+    return g, P, ro, vo
+
+
+def test_config5_three_iterations_match_oracle(config5):
+    from dynosam_amd.optimizer import Context
+    g, P, ro, vo = config5
+    c = Context(); c.upload(g)
+    assert abs(c.error() - ro.error_before) <= 1e-11 * ro.error_before
+    r = c.optimize(P)
+    assert trace(r) == trace(ro) and r.iterations == ro.iterations == 3
+    for i in range(ro.trace_len):
+        if np.isfinite(ro.trace_error[i]):
+            assert abs(r.trace_error[i] - ro.trace_error[i]) <= 1e-6 * ro.trace_error[i], i
+    assert abs(r.error_after - ro.error_after) <= 1e-6 * ro.error_after
+    assert np.abs(c.values() - vo).max() <= 1e-5
+    c.close()
+
+
+@pytest.mark.parametrize("world", [4])
+def test_config5_sharded_three_iterations_match_oracle(config5, world):
+    from test_gpu_multirank import run_ranks
+    g, P, ro, vo = config5
+
+    def work(ctx):
+        r = ctx.optimize(P)
+        return r, ctx.values()
+
+    res = run_ranks(g, world, work)
+    for r, v in res:
+        assert trace(r) == trace(ro) and r.iterations == ro.iterations
+        assert abs(r.error_before - ro.error_before) <= 1e-11 * ro.error_before
+        assert abs(r.error_after - ro.error_after) <= 1e-6 * ro.error_after
+        assert np.abs(v - vo).max() <= 1e-5
+    for _r, v in res[1:]:
+        assert np.array_equal(v, res[0][1])       # replicas bitwise identical after the consolidation
+
+
+def test_full_density_window_matches_window_oracle(oracle):
+    """BASELINE config 3 at the density it is quoted on: 20-keyframe windows with overlap 4 over the config-2 stream
+    (40 static + 10 dynamic tracks born per frame, 5 objects).  Window 1 (no prior): its marginal against the oracle's partial
+    elimination at the same values.  Window 2 (the GPU-made linear containers + dense prior on poses AND points + 16 new
+    frames): LM against the window oracle to convergence."""
+    from dynosam_amd import sliding_window as SW
+    from dynosam_amd.optimizer import Context
+    from oracle import window_oracle as WO
+    frames = 40
+    g = synth.make_hybrid_graph(synth.config(2, frames=frames, static_points=40 * frames, dynamic_points_per_object=2 * frames))
+    ctx = Context()
+    sw = SW.SlidingWindowOptimization(window_size=20, overlap=4, ctx=ctx)
+    wins = []
+    for k, blocks, vals in SW.frame_stream(g):
+        r = sw.update(blocks, vals, k)
+        if r.optimized:
+            wins.append(r)
+    assert len(wins) == 2
+    w1, w2 = wins
+    assert w1.graph.n_factors > 8000 and w2.graph.n_factors > 8000
+    # ---- window 1: the marginal at the GPU's optimum ----
+    state1 = np.array([w1.result[int(k)][1] for k in w1.graph.var_keys])
+    o1 = WO.WindowOracle(w1.graph)
+    marg1 = [int(k) for k in w1.graph.var_keys if int(k) not in {int(q) for q in w2.graph.var_keys}]
+    rblocks, rprior = o1.marginalize(marg1, state1)
+    p1 = w1.prior
+    assert np.array_equal(p1.keys, rprior.keys) and (w1.graph.var_type[[w1.graph.key_index(int(k)) for k in p1.keys]] == 1).any()   # names points too
+    sc = np.abs(rprior.Lambda).max()
+    assert np.abs(p1.Lambda - rprior.Lambda).max() <= 1e-8 * sc
+    assert np.abs(p1.eta - rprior.eta).max() <= 1e-8 * max(1.0, np.abs(rprior.eta).max())
+    assert abs(p1.c - rprior.c) <= 1e-8 * max(1.0, abs(rprior.c))
+    got = {(b.type, int(s)): (b.meas[i], b.consts[i]) for b in w1.prior_blocks for i, s in enumerate(b.slot)}
+    ref = {(b.type, int(s)): (b.meas[i], b.consts[i]) for b in rblocks for i, s in enumerate(b.slot)}
+    assert got.keys() == ref.keys() and len(got) > 100
+    for key in ref:
+        assert np.abs(got[key][0] - ref[key][0]).max() <= 1e-11 * max(1.0, np.abs(ref[key][0]).max())
+        assert np.abs(got[key][1] - ref[key][1]).max() <= 1e-10 * max(1.0, np.abs(ref[key][1]).max())
+    # ---- window 2: LM with containers + prior, same input graph on both sides ----
+    o2 = WO.WindowOracle(w2.graph)
+    assert w2.graph.prior is not None and any(b.type & G.F_LINEARIZED for b in w2.graph.blocks)
+    ro, tr = o2.optimize()
+    r = w2.report
+    assert abs(r.error_before - ro.error_before) <= 1e-9 * ro.error_before
+    assert trace(r) == [bool(t[2]) for t in tr]
+    assert r.iterations == ro.iterations and r.inner_iterations == ro.inner_iterations
+    assert abs(r.error_after - ro.error_after) <= 1e-6 * ro.error_after
+    state2 = np.array([w2.result[int(k)][1] for k in w2.graph.var_keys])
+    assert np.abs(state2 - o2.state).max() <= 1e-5
+    ctx.close()
+
+
+def test_stereo_static_graph_with_cheirality_matches_oracle(oracle):
+    """row a2: GenericStereoFactor<Pose3, Point3> as the static factor of a whole scenario (the shipped
+    static_formulation_type = 2); 5 landmarks start behind one of their cameras, so the first linearisations contain
+    cheirality factors (error 2 fx per row, zero Jacobian) and the optimiser has to pull the points back in front."""
+    from dynosam_amd.optimizer import Context
+    g = synth.to_stereo_static(synth.make_hybrid_graph(synth.config(1)), behind=5)
+    og = oracle.OracleGraph(g)
+    c = Context(); c.upload(g)
+    J, b, e = c.linearize()
+    Jr, br, er = og.linearize()
+    blk = [x for x in g.blocks if x.type == G.F_STEREO_POINT][0]
+    f0 = sum(x.count for x in g.blocks[:g.blocks.index(blk)])
+    cheir = [i for i in range(blk.count) if np.abs(Jr[f0 + i]).max() == 0.0]
+    assert len(cheir) >= 5
+    fx, k = blk.consts[0, 0], blk.huber_k[0]
+    for i in cheir:
+        # whitened error 2 fx / sigma on every row, Huber loss k (|e| - k / 2), zero Jacobian
+        n = 2.0 * fx * blk.noise[i, 0] * np.sqrt(3.0)
+        assert np.abs(J[f0 + i]).max() == 0.0 and abs(e[f0 + i] - k * (n - 0.5 * k)) <= 1e-12 * k * n
+    assert np.abs(J - Jr).max() <= 1e-11 * np.abs(Jr).max()
+    assert np.abs(b - br).max() <= 1e-11 * max(1.0, np.abs(br).max())
+    assert np.abs(e - er).max() <= 1e-11 * max(1.0, np.abs(er).max())
+    d, dec = c.solve_damped(1e-3)
+    bad, dr, decr = og.solve_damped(1e-3)
+    assert bad == 0 and np.abs(d - dr).max() <= 1e-6 * max(1.0, np.abs(dr).max()) and abs(dec - decr) <= 1e-8 * abs(decr)
+    r = c.optimize()
+    ro, _ = og.optimize()
+    assert trace(r) == trace(ro) and r.iterations == ro.iterations and r.inner_iterations == ro.inner_iterations
+    assert abs(r.error_after - ro.error_after) <= 1e-6 * ro.error_after
+    assert np.abs(c.values() - og.state()).max() <= 1e-5
+    c.close()
+
+
+def test_huber_on_smoothing_blocks_matches_oracle(oracle):
+    """the ABI accepts huber_k on any block: HybridSmoothingFactor (numerical Jacobians) under Robust(Huber) must
+    linearise, evaluate and solve like the oracle's generic Robust::WhitenSystem (was silently ignored)"""
+    from dynosam_amd.optimizer import Context
+    g = synth.make_hybrid_graph(synth.config(1, frames=14, static_points=60, dynamic_points_per_object=24, seed=8))
+    blocks = []
+    for b in g.blocks:
+        if b.type == G.F_HYBRID_SMOOTHING:
+            b = G.FactorBlock(b.type, b.slot, b.var_idx, b.meas, b.noise, np.full(b.count, 0.5), b.consts)
+        blocks.append(b)
+    g = G.FlatGraph(g.var_keys, g.var_type, g.var_state, blocks, dict(g.meta))
+    og = oracle.OracleGraph(g)
+    c = Context(); c.upload(g)
+    J, b, e = c.linearize()
+    Jr, br, er = og.linearize()
+    sm = [x for x in g.blocks if x.type == G.F_HYBRID_SMOOTHING][0]
+    f0 = sum(x.count for x in g.blocks[:g.blocks.index(sm)])
+    # the test only means something if some smoothing factors are beyond the Huber threshold at the initial values
+    wn = np.linalg.norm(br[f0:f0 + sm.count], axis=1)
+    assert (wn > 0.5).any() and (wn < 0.5).any()
+    assert np.abs(J - Jr).max() <= 1e-9 * np.abs(Jr).max()        # central differences: 1/(2 delta) amplifies rounding
+    assert np.abs(b - br).max() <= 1e-11 * max(1.0, np.abs(br).max())
+    assert np.abs(e - er).max() <= 1e-11 * max(1.0, np.abs(er).max())
+    assert abs(c.error() - og.error()) <= 1e-11 * og.error()
+    r = c.optimize()
+    ro, _ = og.optimize()
+    assert trace(r) == trace(ro) and abs(r.error_after - ro.error_after) <= 1e-6 * ro.error_after
+    c.close()

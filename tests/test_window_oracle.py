@@ -71,3 +71,28 @@ def test_window_lm_converges_and_matches_the_c_oracle_without_priors():
     og = O.OracleGraph(g); og.set_dense(True)
     r2, _ = og.optimize()
     assert r1.iterations == r2.iterations and abs(r1.error_after - r2.error_after) <= 1e-7 * r2.error_after
+
+
+def test_schur_solve_of_the_window_oracle_equals_its_dense_solve():
+    """full-density windows solve the damped normal equations through the Schur complement of the uncoupled points
+    (WindowOracle._solve); it must be the same system as the plain dense Cholesky the small windows use"""
+    g = synth.make_hybrid_graph(synth.config(1, frames=10, static_points=60, dynamic_points_per_object=16, static_track=(3, 6),
+                                             dynamic_track=(3, 6), seed=7))
+    # marginalise everything older than frame 4 except the points born in frames 2-3: they stay, next to marginalised poses
+    keys = [int(k) for k, f, t in zip(g.var_keys, g.meta["var_frame"], g.var_type) if f < 4 and not (t == 1 and f >= 2)]
+    w = WO.WindowOracle(g)
+    blocks, prior = w.marginalize(keys, g.var_state)        # the next window: containers + a prior that names points
+    keep = np.array([i for i, k in enumerate(g.var_keys) if int(k) not in set(keys)])
+    remap = -np.ones(g.n_vars, int); remap[keep] = np.arange(len(keep))
+    for b in blocks:
+        b.var_idx = remap[b.var_idx].astype(np.int32)
+    g2 = FlatGraph(g.var_keys[keep], g.var_type[keep], g.var_state[keep], blocks, {}, prior)
+    w2 = WO.WindowOracle(g2)
+    assert 0 < len(w2.free_pts) < (g2.var_type == 1).sum()  # some points are coupled by the prior, the others are eliminated
+    H, gv, _ = w2.normal_equations(g2.var_state)
+    for lam in (1e-5, 1.0):
+        w2.SCHUR_MIN_DIM = 10 ** 9
+        dense = w2._solve(H, gv, lam)
+        w2.SCHUR_MIN_DIM = 0
+        schur = w2._solve(H, gv, lam)
+        assert np.abs(schur - dense).max() <= 1e-6 * max(1.0, np.abs(dense).max())   # (cond ~ 1e12: the damped-solve tolerance used throughout)

@@ -171,7 +171,8 @@ def test_full_size_properties_config2(lib_loaded, oracle):
     g = synth.make_hybrid_graph(synth.config(2))
     c, og = ctx_for(g), oracle.OracleGraph(g)
     assert abs(c.error() - og.error()) <= 1e-12 * og.error()
-    # three outer iterations against the oracle (the full CPU solve takes too long for a test)
+    # three outer iterations against the oracle here; the WHOLE solve to convergence is compared in
+    # tests/test_gpu_parity_full.py::test_config2_full_convergence_matches_oracle
     P = LevenbergMarquardtParams()
     P.max_iterations = 3
     r = c.optimize(P)

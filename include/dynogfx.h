@@ -108,7 +108,10 @@ typedef struct {
  * leaves on its separator:   error(x) = 0.5 dx' Lambda dx - eta' dx + c ,   dx = stacked Local(lin_k, x_k)
 * (tangent order [omega, v] per pose, x - lin per point, keys in the order given; a Point3 named here is kept in the reduced
  * system instead of being Schur-eliminated).  Relinearisation follows
- * gtsam::LinearContainerFactor: Hessian Lambda unchanged, gradient eta - Lambda dx. */
+ * gtsam::LinearContainerFactor: Hessian Lambda unchanged, gradient eta - Lambda dx.
+ * Sharded graphs (world_size > 1): the prior is ONE factor and is handed to ONE rank (the one whose window holds its keys:
+ * rank 0 for a sliding-window marginal); every other rank passes the same `keys` with Lambda == eta == NULL ("structure only"),
+ * so that all ranks keep the same Point3 variables in the reduced system. */
 typedef struct {
   int32_t n_keys;
   int32_t dim;                /* sum of the tangent dimensions: 6 per Pose3, 3 per Point3   */

@@ -159,3 +159,75 @@ def test_one_rank_in_library_rccl_path():
     assert abs(r1.error_after - r0.error_after) <= 1e-6 * r0.error_after
     assert np.abs(c1.values() - c.values()).max() <= 1e-5
     c.close(); c1.close()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_wcme_graph_with_point_chains(world):
+    """world-centric motion formulation on the sharded path: the per-frame points of a tracklet are coupled by
+    LandmarkMotionTernaryFactors and eliminated as chains; FlatGraph.shard keeps every chain whole on the rank of its
+    earliest frame (a chain may reach into the next rank's separator).  Damped solve and LM trace equal the single context."""
+    from dynosam_amd.optimizer import Context
+    g = synth.make_wcme_graph(synth.config(1, frames=90, objects=2, static_points=360, dynamic_points_per_object=60, seed=12))
+    c = Context(); c.upload(g)
+    d_ref, dec_ref = c.solve_damped(1e-3)
+    r0 = c.optimize()
+    v0 = c.values()
+
+    def work(ctx):
+        d = ctx.solve_damped(1e-3)
+        ctx.set_values(g.var_state)
+        r = ctx.optimize()
+        return d, r, ctx.values()
+
+    res = run_ranks(g, world, work)
+    for (d, dec), r, v in res:
+        assert np.abs(d - d_ref).max() <= 1e-6 * max(1.0, np.abs(d_ref).max()) and abs(dec - dec_ref) <= 1e-6 * abs(dec_ref)
+        assert r.iterations == r0.iterations and r.inner_iterations == r0.inner_iterations
+        assert [r.trace_accepted[i] for i in range(r.trace_len)] == [r0.trace_accepted[i] for i in range(r0.trace_len)]
+        assert abs(r.error_after - r0.error_after) <= 1e-6 * r0.error_after
+        assert np.abs(v - v0).max() <= 1e-5
+    for _d, _r, v in res[1:]:
+        assert np.array_equal(v, res[0][2])
+
+
+def test_sharded_window_with_containers_and_a_prior_on_points():
+    """a sliding-window graph on the sharded path: linear containers (ordinary factor blocks of the shard) and the dense
+    Hessian-form prior - ONE factor, carried by rank 0, naming poses AND points (kept in rank 0's reduced system).  Built
+    from the marginal of the first frames of a long stream so that the ranks' windows are long enough to be dissected."""
+    from dynosam_amd.optimizer import Context
+    from dynosam_amd.graph import FlatGraph
+    g = synth.make_hybrid_graph(synth.config(1, frames=110, objects=2, static_points=660, dynamic_points_per_object=110, seed=14))
+    vt, vf = g.var_type, g.meta["var_frame"]
+    keys = [int(k) for k, t, f in zip(g.var_keys, vt, vf) if (t == 0 and f < 6) or (t != 0 and f < 3)]   # old poses, only the oldest points
+    c = Context(); c.upload(g)
+    blocks, prior = c.marginalize(keys)
+    assert (g.var_type[[g.key_index(int(k)) for k in prior.keys]] == 1).any()       # the marginal names retained points
+    ks = set(keys)
+    keep = np.array([i for i, k in enumerate(g.var_keys) if int(k) not in ks])
+    remap = -np.ones(g.n_vars, int); remap[keep] = np.arange(len(keep))
+    out = []
+    for b in blocks:
+        b2 = b.subset(np.ones(b.count, bool)); b2.var_idx = remap[b.var_idx].astype(np.int32); out.append(b2)
+    rng = np.random.default_rng(3)
+    st = g.var_state[keep].copy()
+    st[g.var_type[keep] == 1, :3] += 0.01 * rng.normal(size=(int((g.var_type[keep] == 1).sum()), 3))    # away from the linearisation point
+    g2 = FlatGraph(g.var_keys[keep], g.var_type[keep], st, out, {}, prior)
+    c.upload(g2)
+    d_ref, dec_ref = c.solve_damped(1e-3)
+    c.set_values(g2.var_state)
+    r0 = c.optimize()
+    v0 = c.values()
+
+    def work(ctx):
+        d = ctx.solve_damped(1e-3)
+        ctx.set_values(g2.var_state)
+        r = ctx.optimize()
+        return d, r, ctx.values()
+
+    res = run_ranks(g2, 2, work)
+    for (d, dec), r, v in res:
+        assert np.abs(d - d_ref).max() <= 1e-6 * max(1.0, np.abs(d_ref).max()) and abs(dec - dec_ref) <= 1e-6 * abs(dec_ref)
+        assert r.iterations == r0.iterations and r.inner_iterations == r0.inner_iterations
+        assert abs(r.error_after - r0.error_after) <= 1e-6 * r0.error_after
+        assert np.abs(v - v0).max() <= 1e-5
+    assert np.array_equal(res[0][2], res[1][2])

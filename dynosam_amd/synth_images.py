@@ -69,3 +69,32 @@ def make_pair(width=640, height=480, objects=3, seed=4, max_flow=8.0):
     txi, tyi = np.clip(np.round(tx).astype(int), 0, width - 1), np.clip(np.round(ty).astype(int), 0, height - 1)
     valid = inb & (mask1[tyi, txi] == mask0)
     return dict(rgb0=rgb0, rgb1=rgb1, mask0=mask0, mask1=mask1, flow_gt=flow.astype(np.float32), valid=valid, u_bg=u_bg)
+
+
+def make_sequence(width=640, height=480, objects=3, frames=10, seed=4, max_flow=6.0):
+    """a short stream for the composed tracker: the static scene slides by an integer flow per frame, every object moves rigidly
+    (constant translation + small rotation / scale per frame about its own moving centre).  returns (rgb [F,H,W,3] u8, mask [F,H,W] i32)."""
+    rng = np.random.default_rng(seed)
+    ys, xs = np.mgrid[0:height, 0:width].astype(np.float64)
+    bg = _texture(rng)
+    u_bg = np.round(rng.uniform(-max_flow, max_flow, 2))
+    objs = []
+    for j in range(objects):
+        c = np.array([rng.uniform(0.25, 0.75) * width, rng.uniform(0.3, 0.7) * height])
+        half = np.array([rng.uniform(35, 70), rng.uniform(30, 55)])
+        objs.append(dict(c=c, half=half, th=rng.uniform(-0.01, 0.01), sc=1.0 + rng.uniform(-0.004, 0.004), t=rng.uniform(-max_flow, max_flow, 2), tex=_texture(rng)))
+    rgbs, masks = [], []
+    for f in range(frames):
+        img = bg(xs - f * u_bg[0], ys - f * u_bg[1])
+        mask = np.zeros((height, width), np.int32)
+        for j, o in enumerate(objs):
+            th, sc = f * o["th"], o["sc"] ** f
+            Mi = np.linalg.inv(sc * np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]]))
+            cf = o["c"] + f * o["t"]
+            dx, dy = xs - cf[0], ys - cf[1]
+            ox, oy = Mi[0, 0] * dx + Mi[0, 1] * dy + o["c"][0], Mi[1, 0] * dx + Mi[1, 1] * dy + o["c"][1]
+            inside = (np.abs(ox - o["c"][0]) <= o["half"][0]) & (np.abs(oy - o["c"][1]) <= o["half"][1])
+            img = np.where(inside[..., None], o["tex"](ox, oy), img)
+            mask = np.where(inside, j + 1, mask)
+        rgbs.append(np.clip(np.round(127.5 + 105.0 * img), 0, 255).astype(np.uint8)); masks.append(mask)
+    return np.stack(rgbs), np.stack(masks)

@@ -194,4 +194,4 @@ def track_dynamic(kp, prev_label, age, tracklet_id, flow, motion_mask, detection
             hw = int(np.floor(np.sqrt(v)))
             det[yy, max(0, x - hw):min(W - 1, x + hw) + 1] = 0
     return dict(code=code, label=label, new_age=new_age, new_tracklet_id=new_tid, flow=fl, predicted_kp=pk,
-                next_tracklet_id=next_tracklet_id)
+                next_tracklet_id=next_tracklet_id, detection_mask=det)

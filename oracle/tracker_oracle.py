@@ -1,0 +1,222 @@
+"""CPU restatement of the bookkeeping of FeatureTracker::track - numpy / plain Python.
+
+TEST INFRASTRUCTURE ONLY (imported by tests/ and bench.py's cpu leg; never by dynosam_amd/).
+
+Follows, line by line where the logic is order dependent:
+  dynosam/src/frontend/vision/FeatureTracker.cc
+      :73-192    track             composition: objectDetection -> static track || dynamic track -> Frame
+      :339-498   trackDynamic      (the per-feature propagation itself is oracle/flow_oracle.py::track_dynamic)
+      :864-1012  sampleDynamic     candidates = pixels with detection mask set, label to sample, non-zero flow, inside the
+                                   shrunken image; per object ANMS (RangeTree) to max_features - num_track; age 0, new ids
+      :1014-1147 requiresSampling  new object | > 80 % of the tracks about to expire | < min_dynamic_tracks | IoU(detection
+                                   box, box of the tracks) < min_dynamic_mask_iou
+  dynosam/src/frontend/anms/anms.cc:278-361   anms::RangeTree (brute-force square queries instead of the range tree)
+  dynosam/src/frontend/anms/NonMaximumSupression.cc:33-56   the response sort in front of it
+Undefined in the reference and fixed here (and in the product): the candidate order inside an object (a tbb::parallel_for over
+rows fills the vectors; all responses are equal) = row-major; num_ret <= 0 -> nothing, num_ret == 1 -> the first keypoint (the
+reference divides by num_ret - 1 / num_ret).  PARITY UNPINNED against the binary (the reference has no test for any of this).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def anms_range_tree(xy: np.ndarray, num_ret: int, tolerance: float, cols: int, rows: int) -> np.ndarray:
+    """indices (into xy) of the kept keypoints, in selection order"""
+    xy = np.asarray(xy, np.float32).reshape(-1, 2)
+    n = len(xy)
+    K = int(num_ret)
+    if n == 0 or K <= 0:
+        return np.zeros(0, np.int64)
+    if K == 1:
+        return np.zeros(1, np.int64)
+    exp1 = rows + cols + 2 * K
+    exp2 = 4 * cols + 4 * K + 4 * rows * K + rows * rows + cols * cols - 2 * rows * cols + 4 * rows * cols * K
+    exp3 = np.sqrt(float(exp2))
+    exp4 = float(K - 1)
+    c_round = lambda v: float(np.sign(v) * np.floor(abs(v) + 0.5))     # C round(): half away from zero
+    sol1, sol2 = -c_round((exp1 + exp3) / exp4), -c_round((exp1 - exp3) / exp4)
+    high = int(sol1 if sol1 > sol2 else sol2)
+    low = int(np.floor(np.sqrt(float(n) / K)))
+    tol = np.float32(tolerance)
+    Kf = np.float32(K)
+    kmin = int(c_round(float(Kf - Kf * tol)))
+    kmax = int(c_round(float(Kf + Kf * tol)))
+    tx = xy[:, 0].astype(np.int64) & 0xFFFF      # tree coordinates: (u16) truncation
+    ty = xy[:, 1].astype(np.int64) & 0xFFFF
+    result, prevwidth = [], -1
+    while True:
+        width = low + int((high - low) / 2)       # C integer division truncates toward zero
+        if width == prevwidth or low > high:
+            return np.array(result, np.int64)
+        result = []
+        included = np.ones(n, bool)
+        for i in range(n):
+            if not included[i]:
+                continue
+            included[i] = False
+            result.append(i)
+            w32 = np.float32(width)
+            minx, maxx = int(xy[i, 0] - w32), int(xy[i, 0] + w32)
+            miny, maxy = int(xy[i, 1] - w32), int(xy[i, 1] + w32)
+            minx, miny = max(minx, 0), max(miny, 0)
+            x0, x1, y0, y1 = minx & 0xFFFF, maxx & 0xFFFF, miny & 0xFFFF, maxy & 0xFFFF
+            if x1 < x0:
+                x0, x1 = x1, x0
+            if y1 < y0:
+                y0, y1 = y1, y0
+            included &= ~((tx >= x0) & (tx <= x1) & (ty >= y0) & (ty <= y1))
+        if kmin <= len(result) <= kmax:
+            return np.array(result, np.int64)
+        if len(result) < kmin:
+            high = width - 1
+        else:
+            low = width + 1
+        prevwidth = width
+
+
+def within_shrunken(x, y, w, h, shrink_row, shrink_col):
+    """FeatureTrackerBase::isWithinShrunkenImage on (col, row) = static_cast<int>(kp)"""
+    c, r = np.asarray(x).astype(np.int64), np.asarray(y).astype(np.int64)
+    return (r > shrink_row) & (r < h - shrink_row) & (c > shrink_col) & (c < w - shrink_col)
+
+
+def sample_dynamic(motion_mask, flow, detection_mask, objects, n_needed, shrink_row=0, shrink_col=0, tolerance=0.01, next_tracklet_id=0):
+    """FeatureTracker::sampleDynamic.  returns dict(label, tracklet_id, kp, flow, predicted_kp, n_candidates, n_sampled, n_zero_flow,
+    next_tracklet_id); objects in the order given, ANMS order inside an object."""
+    h, w = motion_mask.shape
+    det = np.ones((h, w), bool) if detection_mask is None else (np.asarray(detection_mask) != 0)
+    fx, fy = flow[..., 0], flow[..., 1]
+    out = dict(label=[], tracklet_id=[], kp=[], flow=[], predicted_kp=[], n_candidates=[], n_sampled=[], n_zero_flow=[])
+    ys_all, xs_all = np.mgrid[0:h, 0:w]
+    inside = within_shrunken(xs_all, ys_all, w, h, shrink_row, shrink_col)
+    tid = int(next_tracklet_id)
+    for obj, need in zip(objects, n_needed):
+        sel = det & (motion_mask == obj) & (obj != 0)
+        zero = sel & ((fx == 0) | (fy == 0))
+        cand = sel & ~zero & inside
+        ys, xs = np.nonzero(cand)                    # row-major
+        out["n_candidates"].append(len(xs)); out["n_zero_flow"].append(int(zero.sum()))
+        if len(xs) == 0:
+            out["n_sampled"].append(0)
+            continue
+        keep = anms_range_tree(np.stack([xs, ys], -1).astype(np.float32), int(need), tolerance, w, h)
+        out["n_sampled"].append(len(keep))
+        for i in keep:
+            x, y = int(xs[i]), int(ys[i])
+            f = (float(fx[y, x]), float(fy[y, x]))
+            out["label"].append(int(obj)); out["tracklet_id"].append(tid); tid += 1
+            out["kp"].append((float(x), float(y))); out["flow"].append(f); out["predicted_kp"].append((x + f[0], y + f[1]))
+    res = {k: np.array(v) for k, v in out.items()}
+    for k in ("kp", "flow", "predicted_kp"):
+        res[k] = res[k].reshape(-1, 2)
+    res["next_tracklet_id"] = tid
+    return res
+
+
+def bounding_rect(kp):
+    """cv::boundingRect of float points (toOpenCV keypoints): [floor(min), floor(max)] inclusive -> (x, y, w, h) [recalled]"""
+    x0, y0 = int(np.floor(kp[:, 0].min())), int(np.floor(kp[:, 1].min()))
+    x1, y1 = int(np.floor(kp[:, 0].max())), int(np.floor(kp[:, 1].max()))
+    return (x0, y0, x1 - x0 + 1, y1 - y0 + 1)
+
+
+def iou(a, b):
+    """utils::calculateIoU of two cv::Rect (x, y, w, h): intersection / union of the areas"""
+    ax0, ay0, ax1, ay1 = a[0], a[1], a[0] + a[2], a[1] + a[3]
+    bx0, by0, bx1, by1 = b[0], b[1], b[0] + b[2], b[1] + b[3]
+    iw, ih = max(0, min(ax1, bx1) - max(ax0, bx0)), max(0, min(ay1, by1) - max(ay0, by0))
+    inter = iw * ih
+    union = a[2] * a[3] + b[2] * b[3] - inter
+    return inter / union if union > 0 else 0.0
+
+
+def requires_sampling(detected_objects, inner_boxes, tracked, known_objects, max_age=25, age_buffer=3, min_tracks=20, min_iou=0.4):
+    """FeatureTracker::requiresSampling.  tracked: {object: dict(age [n], kp [n,2])} of this frame's tracked features;
+    known_objects: labels with a PerObjectStatus in info_ (created by the tracking loop).  returns (objects to sample - ascending,
+    as the std::set iterates -, {object: reasons})"""
+    expiry = max_age - max(3, age_buffer)
+    out, why = [], {}
+    for obj, box in zip(detected_objects, inner_boxes):
+        if obj in known_objects:
+            if obj not in tracked or len(tracked[obj]["age"]) == 0:
+                continue                                     # "found in mask and info but missing tracked features. Skipping"
+            ages, kp = np.asarray(tracked[obj]["age"]), np.asarray(tracked[obj]["kp"], np.float64).reshape(-1, 2)
+            n = len(ages)
+            many_old = float((ages > expiry).sum()) / float(n) > 0.8
+            too_few = n < min_tracks
+            small = iou(tuple(box), bounding_rect(kp)) < min_iou
+            if many_old or too_few or small:
+                out.append(int(obj)); why[int(obj)] = dict(many_old=many_old, too_few=too_few, small_iou=small, new=False)
+        else:
+            out.append(int(obj)); why[int(obj)] = dict(many_old=False, too_few=False, small_iou=False, new=True)
+    return sorted(out), why
+
+
+def _status():
+    return dict(num_previous_track=0, num_track=0, num_sampled=0, num_zero_flow=0, num_outside_shrunken_image=0,
+                num_tracked_with_background_label=0, num_tracked_with_different_label=0, object_new=False, object_resampled=False)
+
+
+def track_dynamic_frame(prev_dynamic, motion_mask, flow, boundary, next_tracklet_id, max_features=50, max_age=25, age_buffer=3, min_tracks=20,
+                        min_iou=0.3, min_distance=2, shrink_row=0, shrink_col=0):
+    """FeatureTracker::trackDynamic (:339-498) for one frame: propagation of the previous dynamic features (flow_oracle.track_dynamic),
+    info_ bookkeeping, requiresSampling, sampleDynamic.  prev_dynamic: None or dict(tracklet_id, predicted_kp, age, object_id);
+    boundary: dict(boundary_mask, objects, inner_boxes) of this frame's object mask; flow: the k -> k+1 flow image [H, W, 2] f32.
+    returns (dict of the frame's dynamic features, objects sampled, per-object status, next tracklet id)"""
+    from . import flow_oracle as FO
+    status, tracked = {}, {}
+    det = boundary["boundary_mask"]
+    feats = dict(tracklet_id=[], kp=[], age=[], object_id=[], flow=[], predicted_kp=[])
+    tid = int(next_tracklet_id)
+    if prev_dynamic is not None and len(prev_dynamic["tracklet_id"]):
+        r = FO.track_dynamic(prev_dynamic["predicted_kp"], prev_dynamic["object_id"], prev_dynamic["age"], prev_dynamic["tracklet_id"], flow, motion_mask,
+                             detection_mask=boundary["boundary_mask"], shrink_row=shrink_row, shrink_col=shrink_col, max_age=max_age,
+                             min_distance=min_distance, next_tracklet_id=tid)
+        tid, det = r["next_tracklet_id"], r["detection_mask"]
+        per_obj = {}
+        for i, code in enumerate(r["code"]):
+            if code == FO.MASKED_OUT:
+                continue
+            lab = int(r["label"][i])
+            s = status.setdefault(lab, _status())
+            s["num_previous_track"] += 1
+            if lab == 0:
+                s["num_tracked_with_background_label"] += 1
+            if lab != int(prev_dynamic["object_id"][i]):
+                s["num_tracked_with_different_label"] += 1
+            if code == FO.OUTSIDE_SHRUNKEN:
+                s["num_outside_shrunken_image"] += 1
+            elif code == FO.ZERO_FLOW:
+                s["num_zero_flow"] += 1
+            elif code == FO.KEPT:
+                s["num_track"] += 1
+                per_obj.setdefault(lab, []).append(i)
+        for lab in sorted(per_obj):                     # gtsam::FastMap iterates in ascending label order (:487-489)
+            for i in per_obj[lab]:
+                feats["tracklet_id"].append(int(r["new_tracklet_id"][i])); feats["kp"].append(tuple(prev_dynamic["predicted_kp"][i]))
+                feats["age"].append(int(r["new_age"][i])); feats["object_id"].append(lab)
+                feats["flow"].append(tuple(r["flow"][i])); feats["predicted_kp"].append(tuple(r["predicted_kp"][i]))
+            idx = per_obj[lab]
+            tracked[lab] = dict(age=np.array([int(r["new_age"][i]) for i in idx]), kp=np.array([prev_dynamic["predicted_kp"][i] for i in idx], np.float64))
+    to_sample, why = requires_sampling(boundary["objects"], boundary["inner_boxes"], tracked, set(status), max_age, age_buffer, min_tracks, min_iou)
+    for o in to_sample:
+        s = status.setdefault(o, _status())
+        s["object_resampled"] = True
+        if why[o]["new"]:
+            s["object_new"] = True
+    if to_sample:
+        need = [max(max_features - status[o]["num_track"], 0) for o in to_sample]
+        sm = sample_dynamic(motion_mask, flow, det, to_sample, need, shrink_row, shrink_col, 0.01, tid)
+        tid = sm["next_tracklet_id"]
+        for o, nz, ns, nc in zip(to_sample, sm["n_zero_flow"], sm["n_sampled"], sm["n_candidates"]):
+            status[o]["num_zero_flow"] += int(nz)
+            if nc > 0:
+                status[o]["num_sampled"] = int(ns)
+        for i in range(len(sm["label"])):
+            feats["tracklet_id"].append(int(sm["tracklet_id"][i])); feats["kp"].append(tuple(sm["kp"][i])); feats["age"].append(0)
+            feats["object_id"].append(int(sm["label"][i])); feats["flow"].append(tuple(sm["flow"][i])); feats["predicted_kp"].append(tuple(sm["predicted_kp"][i]))
+    out = dict(tracklet_id=np.array(feats["tracklet_id"], np.int64), kp=np.array(feats["kp"], np.float64).reshape(-1, 2), age=np.array(feats["age"], np.int64),
+               object_id=np.array(feats["object_id"], np.int32), flow=np.array(feats["flow"], np.float64).reshape(-1, 2),
+               predicted_kp=np.array(feats["predicted_kp"], np.float64).reshape(-1, 2))
+    return out, to_sample, status, tid

@@ -1,0 +1,1 @@
+#include <gtsam/mock_all.h>

@@ -30,8 +30,8 @@ from dataclasses import dataclass, field
 import numpy as np
 
 from . import symbols as S
-from .graph import (F_BETWEEN_POSE3, F_HYBRID_MOTION, F_HYBRID_SMOOTHING, F_POSE_TO_POINT, F_PRIOR_POSE3, VAR_POINT3, VAR_POSE3,
-                    FactorBlock, FlatGraph)
+from .graph import (F_BETWEEN_POSE3, F_HYBRID_MOTION, F_HYBRID_SMOOTHING, F_LANDMARK_MOTION_POSE, F_LANDMARK_POSE_SMOOTHING, F_LANDMARK_TERNARY,
+                    F_POSE_TO_POINT, F_PRIOR_POSE3, F_STEREO_POINT, VAR_POINT3, VAR_POSE3, FactorBlock, FlatGraph)
 from .synth import act, compose, from12, inverse, to12
 from .tracks import BackendParams
 
@@ -47,12 +47,34 @@ class FramePacket:
     static: np.ndarray = field(default_factory=lambda: np.zeros((0, 4)))     # rows (tracklet, x, y, z)
     dynamic: np.ndarray = field(default_factory=lambda: np.zeros((0, 5)))    # rows (tracklet, object, x, y, z)
     motions: dict = field(default_factory=dict)  # object -> [12] H_W_{k-1,k} (frame-to-frame, global)
+    static_kp: np.ndarray | None = None          # [n_static, 2] left keypoints (u, v): the stereo static updater needs them
+
+
+@dataclass
+class StereoCalibration:
+    """RGBDCamera::getFakeStereoCalib (dynosam_cv/src/RGBDCamera.cc:106-112): the camera's Cal3_S2 + the virtual baseline"""
+    fx: float = 718.856
+    fy: float = 718.856
+    skew: float = 0.0
+    u0: float = 607.1928
+    v0: float = 185.2157
+    baseline: float = 0.1
+    pixel_sigma: float = 2.0          # static_pixel_noise_sigma (BackendParams.cc:57-60): isotropic model of the (uL, uR, v) measurement
+
+    def k6(self):
+        return np.array([self.fx, self.fy, self.skew, self.u0, self.v0, self.baseline])
 
 
 class HybridFormulation:
-    def __init__(self, params: BackendParams | None = None, use_smoothing_factor=True, use_vo=True):
+    def __init__(self, params: BackendParams | None = None, use_smoothing_factor=True, use_vo=True, static_formulation: str = "ptp",
+                 stereo: StereoCalibration | None = None):
+        """static_formulation: "ptp" (static_formulation_type = 0, PoseToPointFactor) or "stereo" (= 2, the shipped default:
+        GenericStereoFactor on the fake stereo rig, StaticFormulationUpdater::StereoProjection)"""
         self.p = params or BackendParams()
         self.use_smoothing_factor, self.use_vo = use_smoothing_factor, use_vo
+        self.static_formulation, self.stereo = static_formulation, stereo or StereoCalibration()
+        self.static_kp = {}                       # tracklet -> {frame: (uL, v)}
+        self.static_outliers = set()
         # ---- map (MapNodes.hpp): everything iterates in id order ----
         self.frames = []                          # frame ids in arrival order
         self.X_init = {}                          # frame -> pose
@@ -172,8 +194,10 @@ class HybridFormulation:
         # ---- updateMapWithMeasurements ----
         st = np.asarray(pk.static, float).reshape(-1, 4)
         dy = np.asarray(pk.dynamic, float).reshape(-1, 5)
-        for row in st:
+        for i, row in enumerate(st):
             self.static_meas.setdefault(int(row[0]), {})[k] = row[1:4]
+            if pk.static_kp is not None:
+                self.static_kp.setdefault(int(row[0]), {})[k] = np.asarray(pk.static_kp[i], float)
         self.frame_static[k] = sorted(set(int(t) for t in st[:, 0]))
         objs = set()
         for row in dy:
@@ -190,20 +214,28 @@ class HybridFormulation:
             self.frontend_motion[(k, int(j))] = from12(np.asarray(m, float))
         # ---- RegularHybridFormulation::preUpdate (HybridEstimator.cc:1160-1190): a known object that re-appears after a
         # frame without update starts a new keyframe ----
+        self._pre_update(k)
+        self._update_static(k)
+        affected = self._update_dynamic(k)
+        self._post_update(k, affected)
+        return n0, len(self.factors)
+
+    def _pre_update(self, k):
         for j in self.frame_objects[k]:
             if j in self.objects_update_data and self.obj_frames[j][0] != k and k > 0 and self.objects_update_data[j] < k - 1:
                 self._force_new_key_frame(k, j)
-        self._update_static(k)
-        affected = self._update_dynamic(k)
+
+    def _post_update(self, k, affected):
         for j, fs in affected.items():            # postUpdate (:1198-1222)
             assert k in fs
             self.objects_update_data[j] = k
-        return n0, len(self.factors)
 
     def _point_noise(self, sigma):
         return np.eye(3).reshape(-1) / sigma
 
     def _update_static(self, k):
+        if self.static_formulation == "stereo":
+            return self._update_static_stereo(k)
         p = self.p
         hub = p.k_huber_3d_points if p.use_robust_kernels else 0.0
         Rs = self._point_noise(p.static_point_noise_sigma)
@@ -221,6 +253,77 @@ class HybridFormulation:
             self._insert(pkey, np.concatenate([act(self.X_init[k], z), np.zeros(9)]), VAR_POINT3)   # hasInitialSensorPose(frame_k)
             self.static_added.add(t)
 
+    # ---- StaticFormulationUpdater::StereoProjection (Formulation-impl.hpp:258-411) ----
+    def _stereo_meas(self, t, f):
+        """(uL, uR, v) of tracklet t at frame f: the left keypoint, and the right one derived from the depth
+        (RGBDCamera::rightKeypoint, RGBDCamera.cc:79-90: uR = uL - fx b / depth)"""
+        c = self.stereo
+        z = self.static_meas[t][f]
+        if t in self.static_kp and f in self.static_kp[t]:
+            uL, v = self.static_kp[t][f]
+        else:                                   # no keypoint carried: project the measured point (exact data: the same pixel)
+            uL, v = c.fx * z[0] / z[2] + c.skew * z[1] / z[2] + c.u0, c.fy * z[1] / z[2] + c.v0
+        return np.array([uL, uL - c.fx * c.baseline / z[2], v])
+
+    def _triangulate(self, poses, pix):
+        """gtsam::triangulateSafe with default TriangulationParameters (rankTolerance 1, no nonlinear refinement): the DLT of
+        triangulatePoint3 on the monocular cameras (left / right of every stereo frame), rank and cheirality checks.
+        [GTSAM-4.2.0 triangulation.h, recalled]  returns the world point or None"""
+        c = self.stereo
+        Kc = np.array([[c.fx, c.skew, c.u0], [0, c.fy, c.v0], [0, 0, 1.0]])
+        A = []
+        for (R, tr), (u, v) in zip(poses, pix):
+            P = Kc @ np.concatenate([R.T, -(R.T @ tr)[:, None]], 1)      # camera projection matrix K [R' | -R' t]
+            A.append(u * P[2] - P[0]); A.append(v * P[2] - P[1])
+        _, sv, Vt = np.linalg.svd(np.array(A))
+        if int((sv > 1.0 * 1e-9 * max(1.0, sv[0])).sum()) < 3 or abs(Vt[-1][3]) < 1e-300:   # rank < 3: underconstrained
+            return None
+        X = Vt[-1][:3] / Vt[-1][3]
+        for R, tr in poses:
+            if (R.T @ (X - tr))[2] <= 0:                                  # TriangulationCheiralityException
+                return None
+        return X
+
+    def _update_static_stereo(self, k):
+        p, c = self.p, self.stereo
+        hub = p.k_huber_3d_points if p.use_robust_kernels else 0.0
+        Rpx = np.eye(3).reshape(-1) / c.pixel_sigma
+        K6 = c.k6()
+        for t in self.frame_static[k]:
+            if t in self.static_outliers:
+                continue
+            pkey = S.StaticLandmarkSymbol(t)
+            if t in self.static_added:
+                self._add_factor(F_STEREO_POINT, [S.CameraPoseSymbol(k), pkey], self._stereo_meas(t, k), Rpx, hub, K6)
+                continue
+            seen = sorted(self.static_meas[t])
+            poses, pix = [], []
+            for f in seen:                        # every stereo camera as a pair of monocular cameras at the INITIAL sensor poses
+                R, tr = self.X_init[f]
+                z = self._stereo_meas(t, f)
+                poses.append((R, tr)); pix.append((z[0], z[2]))
+                if not np.isnan(z[1]):
+                    poses.append((R, tr + R @ np.array([c.baseline, 0.0, 0.0]))); pix.append((z[1], z[2]))
+            X = self._triangulate(poses, pix) if len(poses) >= 2 else None
+            if X is None:
+                self.static_outliers.add(t)       # "mark as outlier for the front-end"
+                continue
+            Kc = np.array([[c.fx, c.skew, c.u0], [0, c.fy, c.v0], [0, 0, 1.0]])
+            err2 = 0.0
+            for (R, tr), (u, v) in zip(poses, pix):
+                q = Kc @ (R.T @ (X - tr))
+                err2 += (q[0] / q[2] - u) ** 2 + (q[1] / q[2] - v) ** 2
+            if np.sqrt(err2) > 3.0:               # reprojection error of the whole camera set (:352-360)
+                self.static_outliers.add(t)
+                continue
+            good = [f for f in seen if (lambda z: z[0] - z[1])(self._stereo_meas(t, f)) > 0.5]   # disparity gate (:376)
+            if len(good) < 2:
+                continue
+            for f in good:
+                self._add_factor(F_STEREO_POINT, [S.CameraPoseSymbol(f), pkey], self._stereo_meas(t, f), Rpx, hub, K6)
+            self._insert(pkey, np.concatenate([X, np.zeros(9)]), VAR_POINT3)
+            self.static_added.add(t)
+
     def _update_dynamic(self, k):
         p = self.p
         hub = p.k_huber_3d_points if p.use_robust_kernels else 0.0
@@ -228,18 +331,7 @@ class HybridFormulation:
         affected = {}                                  # object -> set of frames (result.objects_affected_per_frame)
 
         def point_update(t, obj, f1, f, starting):
-            """HybridFormulation::dynamicPointUpdateCallback"""
-            s0, L_e, H_init = self._motion_info(obj, f1)
-            mkey = S.HybridDynamicKey(t)
-            if t not in self.dyn_in_map:
-                self.dyn_in_map[t] = s0
-                m0 = act(inverse(L_e), act(inverse(H_init), act(self.sensor_pose(f1), self.dyn_meas[t][f1])))   # projectToObject3
-                self._insert(mkey, np.concatenate([m0, np.zeros(9)]), VAR_POINT3)
-                affected.setdefault(obj, set()).add(f1)
-            if starting:
-                self._add_factor(F_HYBRID_MOTION, [S.CameraPoseSymbol(f1), S.ObjectMotionSymbol(obj, f1), mkey], self.dyn_meas[t][f1], Rd, hub, to12(L_e))
-            self._add_factor(F_HYBRID_MOTION, [S.CameraPoseSymbol(f), S.ObjectMotionSymbol(obj, f), mkey], self.dyn_meas[t][f], Rd, hub, to12(L_e))
-            affected.setdefault(obj, set()).add(f)
+            self._dynamic_point_update(t, obj, f1, f, starting, affected, Rd, hub)
 
         for obj in self.frame_objects[k]:
             seen = self.obj_frames[obj]
@@ -263,10 +355,24 @@ class HybridFormulation:
         # ---- objects for which a motion was touched (Formulation-impl.hpp:835-879) ----
         for obj in sorted(affected):
             for idx, f in enumerate(sorted(affected[obj])):
-                self._object_update(obj, f)
+                self._object_update(obj, f, has_motion_pair=idx > 0)      # (:848-853: the first affected frame has no motion pair)
         return affected
 
-    def _object_update(self, obj, f):
+    def _dynamic_point_update(self, t, obj, f1, f, starting, affected, Rd, hub):
+        """HybridFormulation::dynamicPointUpdateCallback"""
+        s0, L_e, H_init = self._motion_info(obj, f1)
+        mkey = S.HybridDynamicKey(t)
+        if t not in self.dyn_in_map:
+            self.dyn_in_map[t] = s0
+            m0 = act(inverse(L_e), act(inverse(H_init), act(self.sensor_pose(f1), self.dyn_meas[t][f1])))   # projectToObject3
+            self._insert(mkey, np.concatenate([m0, np.zeros(9)]), VAR_POINT3)
+            affected.setdefault(obj, set()).add(f1)
+        if starting:
+            self._add_factor(F_HYBRID_MOTION, [S.CameraPoseSymbol(f1), S.ObjectMotionSymbol(obj, f1), mkey], self.dyn_meas[t][f1], Rd, hub, to12(L_e))
+        self._add_factor(F_HYBRID_MOTION, [S.CameraPoseSymbol(f), S.ObjectMotionSymbol(obj, f), mkey], self.dyn_meas[t][f], Rd, hub, to12(L_e))
+        affected.setdefault(obj, set()).add(f)
+
+    def _object_update(self, obj, f, has_motion_pair=True):
         """HybridFormulation::objectUpdateContext"""
         p = self.p
         Hk = S.ObjectMotionSymbol(obj, f)
@@ -292,7 +398,8 @@ class HybridFormulation:
             ftype, fk, meas, noise, hk, consts = self.factors[slot]
             rows.setdefault(ftype, []).append((slot, [index[int(x)] for x in fk] if index is not None else [int(x) for x in fk], meas, noise, hk, consts))
         out = []
-        for ftype in (F_PRIOR_POSE3, F_BETWEEN_POSE3, F_POSE_TO_POINT, F_HYBRID_MOTION, F_HYBRID_SMOOTHING):
+        for ftype in (F_PRIOR_POSE3, F_BETWEEN_POSE3, F_POSE_TO_POINT, F_STEREO_POINT, F_HYBRID_MOTION, F_HYBRID_SMOOTHING, F_LANDMARK_TERNARY,
+                      F_LANDMARK_MOTION_POSE, F_LANDMARK_POSE_SMOOTHING):
             rws = rows.get(ftype)
             if not rws:
                 continue
@@ -320,6 +427,97 @@ class HybridFormulation:
         state = np.array([self.theta[int(k)] for k in keys]).reshape(len(keys), 12)
         blocks = [FactorBlock(*b) for b in self._blocks(0, len(self.factors), index)]
         return FlatGraph(keys, vtype, state, blocks, dict(frames=len(self.frames), objects=len(self.key_frames), n_factors=len(self.factors)))
+
+
+class WorldMotionFormulation(HybridFormulation):
+    """WCME - WorldMotionFormulation (dynosam/src/backend/rgbd/WorldMotionEstimator.cc:151-349) on the same map / update skeleton
+    (Formulation<MAP>::updateDynamicObservations is shared, Formulation-impl.hpp:604-897): one Point3 m_k^i per tracklet AND
+    frame (DynamicLandmarkSymbol = Symbol('m', cantor(tracklet, frame))), a PoseToPointFactor per observation, a
+    LandmarkMotionTernaryFactor (m_{k-1}, m_k, H_k) per consecutive pair, H_k = the world-frame motion k-1 -> k initialised with the
+    frontend's translation and identity rotation (:296-303), BetweenFactor(H_{k-1}, H_k, Identity) smoothing (:341-343)."""
+
+    def __init__(self, params=None, use_smoothing_factor=True, use_vo=True, static_formulation="ptp", stereo=None, motion_ternary_factor_noise_sigma=0.01):
+        super().__init__(params, use_smoothing_factor, use_vo, static_formulation, stereo)
+        self.ternary_sigma = motion_ternary_factor_noise_sigma        # BackendParams.cc:38
+
+    def _pre_update(self, k):
+        pass
+
+    def _post_update(self, k, affected):
+        pass
+
+    def _point_key(self, t, f):
+        return S.DynamicLandmarkSymbol(f, t)
+
+    def _add_point_at(self, t, f, Rd, hub):
+        key = self._point_key(t, f)
+        z = self.dyn_meas[t][f]
+        self._add_factor(F_POSE_TO_POINT, [S.CameraPoseSymbol(f), key], z, Rd, hub)
+        self._insert(key, np.concatenate([act(self.sensor_pose(f), z), np.zeros(9)]), VAR_POINT3)   # X_measured * z (getSafeQuery default)
+
+    def _motion_factor(self, t, obj, f1, f, hub):
+        self._add_factor(F_LANDMARK_TERNARY, [self._point_key(t, f1), self._point_key(t, f), S.ObjectMotionSymbol(obj, f)], (),
+                         np.eye(3).reshape(-1) / self.ternary_sigma, hub)
+
+    def _dynamic_point_update(self, t, obj, f1, f, starting, affected, Rd, hub):
+        add_prev = starting
+        if not add_prev and int(self._point_key(t, f1)) not in self.theta:
+            add_prev = True                       # non-consecutive frames (:175-182)
+        if add_prev:
+            self._add_point_at(t, f1, Rd, hub)
+            affected.setdefault(obj, set()).add(f1)
+        self._add_point_at(t, f, Rd, hub)
+        affected.setdefault(obj, set()).add(f)
+        self._motion_factor(t, obj, f1, f, self.p.k_huber_3d_points if self.p.use_robust_kernels else 0.0)
+        affected[obj].add(f1)
+        self.dyn_in_map[t] = True
+
+    def _object_update(self, obj, f, has_motion_pair=True):
+        if not has_motion_pair:
+            return
+        p = self.p
+        Hk = S.ObjectMotionSymbol(obj, f)
+        if int(Hk) not in self.other_values_in_map:
+            m = self.frontend_motion.get((f, obj), IDENTITY)
+            self._insert(Hk, to12((np.eye(3), m[1])), VAR_POSE3)          # Pose3(Rot3::Identity(), initial_motion.translation())
+            self.other_values_in_map.add(int(Hk))
+        if f < 2 or (f - 1) not in self.frame_objects:
+            return
+        if self.use_smoothing_factor and obj in self.frame_objects[f - 1]:
+            H1 = S.ObjectMotionSymbol(obj, f - 1)
+            if int(H1) in self.other_values_in_map and int(Hk) in self.other_values_in_map:
+                self._add_factor(F_BETWEEN_POSE3, [H1, Hk], to12(IDENTITY), self._iso6(p.constant_object_motion_rotation_sigma, p.constant_object_motion_translation_sigma))
+
+
+class WorldPoseFormulation(WorldMotionFormulation):
+    """WCPE - WorldPoseFormulation (dynosam/src/backend/rgbd/WorldPoseEstimator.cc:89-313): as WCME, but the object variables are its
+    poses L_k (ObjectPoseSymbol), coupled by LandmarkMotionPoseFactor (m_{k-1}, m_k, L_{k-1}, L_k) and LandmarkPoseSmoothingFactor
+    (L_{k-2}, L_{k-1}, L_k).  A pose is initialised by the frontend motion applied to the previous pose estimate, else at the
+    centroid of the object's points with identity rotation (:206-232).  The reference calls objectUpdateContext for EVERY affected
+    frame and has no guard on the smoothing factor: the factor of (k-3, k-2, k-1) is added again in the spin of frame k - restated
+    as is (slot parity).  Deviation: the centroid is taken from this frame's measurements through the sensor pose in fp64 (the
+    reference asks its theta accessor, which cannot yet see the points added in the same spin, and averages in pcl's fp32)."""
+
+    def _motion_factor(self, t, obj, f1, f, hub):
+        self._add_factor(F_LANDMARK_MOTION_POSE, [self._point_key(t, f1), self._point_key(t, f), S.ObjectPoseSymbol(obj, f1), S.ObjectPoseSymbol(obj, f)], (),
+                         np.eye(3).reshape(-1) / self.ternary_sigma, hub)
+
+    def _object_update(self, obj, f, has_motion_pair=True):
+        p = self.p
+        Lk = S.ObjectPoseSymbol(obj, f)
+        if int(Lk) not in self.other_values_in_map:
+            L1 = int(S.ObjectPoseSymbol(obj, f - 1))
+            if (f, obj) in self.frontend_motion and L1 in self.theta:
+                pose = compose(self.frontend_motion[(f, obj)], from12(self.theta[L1]))
+            else:
+                pose = self._centroid(obj, f)
+            self._insert(Lk, to12(pose), VAR_POSE3)
+            self.other_values_in_map.add(int(Lk))
+        if not self.use_smoothing_factor or f < 2 or (f - 1) not in self.frame_objects or (f - 2) not in self.frame_objects:
+            return
+        L1, L2 = S.ObjectPoseSymbol(obj, f - 1), S.ObjectPoseSymbol(obj, f - 2)
+        if all(int(x) in self.other_values_in_map for x in (L2, L1, Lk)):
+            self._add_factor(F_LANDMARK_POSE_SMOOTHING, [L2, L1, Lk], (), self._iso6(p.constant_object_motion_rotation_sigma, p.constant_object_motion_translation_sigma))
 
 
 def packets_from_arrays(frames, X_world, observations, motions):

@@ -200,3 +200,78 @@ def test_backend_loop_formulation_plus_sliding_window_on_the_gpu():
     ini_err = np.mean([np.linalg.norm(from12(pk[k].X_world)[1] - truth[k][1]) for k in range(1, 13)])
     assert est_err < 0.7 * ini_err
     sw.ctx.close()
+
+
+# ---- world-centric formulations and the stereo static updater (widened) ----
+def test_wcme_builder_exact_data_zero_error_and_structure(oracle):
+    pk, info = make_stream()
+    wf = F.WorldMotionFormulation()
+    for p in pk:
+        wf.update(p)
+    g = wf.graph()
+    types = {b.type: b.count for b in g.blocks}
+    # one PoseToPointFactor per dynamic observation in the graph + one ternary factor per consecutive pair
+    n_pts = sum(1 for k in wf.theta if chr(S.symbol_chr(k)) == "m")
+    dyn_ptp = sum(1 for f in wf.factors if f[0] == G.F_POSE_TO_POINT and chr(S.symbol_chr(int(f[1][1]))) == "m")
+    assert dyn_ptp == n_pts and types[G.F_LANDMARK_TERNARY] == n_pts - len(wf.dyn_in_map)   # a tracklet with n points has n - 1 links
+    # motions H_k: frontend translation, identity rotation; smoothing = BetweenFactor(H_{k-1}, H_k, I) once per consecutive pair
+    for k in wf.theta:
+        if chr(S.symbol_chr(k)) == "H":
+            assert np.array_equal(wf.theta[k][:9], np.eye(3).reshape(-1))
+    btw = [f for f in wf.factors if f[0] == G.F_BETWEEN_POSE3 and chr(S.symbol_chr(int(f[1][0]))) == "H"]
+    pairs = [(S.labeled_index(int(f[1][0])), S.labeled_index(int(f[1][1]))) for f in btw]
+    assert len(pairs) == len(set(pairs)) and all(b == a + 1 for a, b in pairs) and len(pairs) >= 4
+    # exact data: the points are exact, the motions are initialised with the wrong (identity) rotation -> optimisable to zero
+    og = oracle.OracleGraph(g)
+    r, _ = og.optimize()
+    assert r.error_after < 1e-10 * max(1.0, r.error_before)
+    # slots: insertion order; the ternary factor of a pair follows the two point factors of that pair
+    assert np.array_equal(np.sort(np.concatenate([b.slot for b in g.blocks])), np.arange(g.n_factors))
+
+
+def test_wcpe_builder_exact_data_and_the_reference_s_repeated_smoothing_factor(oracle):
+    pk, _ = make_stream()
+    wf = F.WorldPoseFormulation()
+    for p in pk:
+        wf.update(p)
+    g = wf.graph()
+    types = {b.type: b.count for b in g.blocks}
+    assert types[G.F_LANDMARK_MOTION_POSE] > 20 and types[G.F_LANDMARK_POSE_SMOOTHING] > 3
+    sm = [tuple(S.labeled_index(int(x)) for x in f[1]) for f in wf.factors if f[0] == G.F_LANDMARK_POSE_SMOOTHING]
+    from collections import Counter
+    c = Counter(sm)
+    assert all(b == a + 1 and d == b + 1 for a, b, d in sm)
+    assert max(c.values()) == 2                    # objectUpdateContext runs for both affected frames of every spin (no guard in the reference)
+    og = oracle.OracleGraph(g)
+    r, _ = og.optimize()
+    assert r.error_after < 1e-10 * max(1.0, r.error_before)
+
+
+def test_stereo_static_updater_triangulates_and_gates(oracle):
+    pk, info = make_stream()
+    cal = F.StereoCalibration(fx=700.0, fy=700.0, u0=320.0, v0=240.0, baseline=0.12, pixel_sigma=1.0)
+    hf = F.HybridFormulation(static_formulation="stereo", stereo=cal)
+    for p in pk:
+        hf.update(p)
+    g = hf.graph()
+    st = [b for b in g.blocks if b.type == G.F_STEREO_POINT]
+    assert len(st) == 1 and st[0].count > 20 and not any(b.type == G.F_POSE_TO_POINT for b in g.blocks)
+    # measurement = (uL, uL - fx b / depth, v); every factor carries the fake stereo calibration
+    assert np.allclose(st[0].consts, cal.k6()[None])
+    assert np.all(st[0].meas[:, 0] - st[0].meas[:, 1] > 0.5)
+    # a tracklet enters with ALL its observations so far once it can be triangulated (two or more frames), then one per frame
+    fac = [f for f in hf.factors if f[0] == G.F_STEREO_POINT]
+    n_frames = len(pk)
+    for i, (a, b) in enumerate(info["s_win"]):
+        n = min(b, n_frames - 1) - a + 1
+        got = sum(1 for f in fac if int(f[1][1]) == int(S.StaticLandmarkSymbol(100 + i)))
+        assert got == (n if n >= 2 else 0), (i, n, got)
+    # exact data: the triangulated initial points are the true points -> zero error
+    og = oracle.OracleGraph(g)
+    assert og.error() < 1e-9
+    # a point at infinity-like disparity is never inserted (disparity gate) and a wild observation rejects the tracklet
+    far = F.FramePacket(0, pk[0].X_world, None, np.array([[900, 0.0, 0.0, 400.0]]), np.zeros((0, 5)), {})
+    far2 = F.FramePacket(1, pk[1].X_world, pk[1].T_k_1_k, np.array([[900, 0.0, 0.0, 400.0]]), np.zeros((0, 5)), {})
+    h2 = F.HybridFormulation(static_formulation="stereo", stereo=cal)
+    h2.update(far); h2.update(far2)
+    assert int(S.StaticLandmarkSymbol(900)) not in h2.theta

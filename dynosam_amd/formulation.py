@@ -184,13 +184,7 @@ class HybridFormulation:
         first = not self.frames
         self.frames.append(k)
         self.X_init[k] = X_k
-        self._insert(S.CameraPoseSymbol(k), to12(X_k), VAR_POSE3)
-        if first:
-            self._add_factor(F_PRIOR_POSE3, [S.CameraPoseSymbol(k)], to12(X_k), self._iso6(self.p.prior_sigma, self.p.prior_sigma))
-        elif self.use_vo:
-            assert pk.T_k_1_k is not None
-            self._add_factor(F_BETWEEN_POSE3, [S.CameraPoseSymbol(self.frames[-2]), S.CameraPoseSymbol(k)], np.asarray(pk.T_k_1_k, float),
-                             self._iso6(self.p.odometry_rotation_sigma, self.p.odometry_translation_sigma))
+        self._add_states(pk, k, X_k, first)
         # ---- updateMapWithMeasurements ----
         st = np.asarray(pk.static, float).reshape(-1, 4)
         dy = np.asarray(pk.dynamic, float).reshape(-1, 5)
@@ -219,6 +213,16 @@ class HybridFormulation:
         affected = self._update_dynamic(k)
         self._post_update(k, affected)
         return n0, len(self.factors)
+
+    def _add_states(self, pk, k, X_k, first):
+        """addInitialVisualState / addVisualInertialStates without IMU (VisionImuBackendModule.hpp:88-243)"""
+        self._insert(S.CameraPoseSymbol(k), to12(X_k), VAR_POSE3)
+        if first:
+            self._add_factor(F_PRIOR_POSE3, [S.CameraPoseSymbol(k)], to12(X_k), self._iso6(self.p.prior_sigma, self.p.prior_sigma))
+        elif self.use_vo:
+            assert pk.T_k_1_k is not None
+            self._add_factor(F_BETWEEN_POSE3, [S.CameraPoseSymbol(self.frames[-2]), S.CameraPoseSymbol(k)], np.asarray(pk.T_k_1_k, float),
+                             self._iso6(self.p.odometry_rotation_sigma, self.p.odometry_translation_sigma))
 
     def _pre_update(self, k):
         for j in self.frame_objects[k]:

@@ -221,15 +221,16 @@ def main():
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/r01_pmc_hbm.txt: separate
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/r02_pmc_hbm.txt: separate
     FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); None if absent."""
-    try:
-        for ln in open(os.path.join(ROOT, "profiles", "r01_pmc_hbm.txt")):
-            t = ln.split()
-            if len(t) >= 5 and t[-1].endswith(kernel):
-                return (float(t[2]) + float(t[3])) * 1024.0
-    except OSError:
-        pass
+    for name in ("r02_pmc_hbm.txt", "r01_pmc_hbm.txt"):
+        try:
+            for ln in open(os.path.join(ROOT, "profiles", name)):
+                t = ln.split()
+                if len(t) >= 5 and t[-1].endswith(kernel):
+                    return (float(t[2]) + float(t[3])) * 1024.0
+        except OSError:
+            pass
     return None
 
 

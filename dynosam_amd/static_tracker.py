@@ -31,6 +31,8 @@ class TrackerParams:                      # TrackerParams.hpp:97-123 defaults
     shrink_row: int = 0
     shrink_col: int = 0
     quality_level: float = 0.001
+    geometric_verification: bool = True   # StaticFeatureTracker.cc:551 (unconditional in the reference)
+    ransac_threshold: float = 5.0         # :632
 
 
 @dataclass
@@ -98,13 +100,20 @@ class KltFeatureTracker:
     def track_static(self, previous: StaticFeatures | None, motion_mask_cur, detection_mask=None, init_pts=None, frame_slot=1):
         """returns (features of the current frame, tracklet ids of `previous` that became outliers).  frame_slot: where the CURRENT
         image is resident (1: the pair is (previous, current); 0: first frame of a stream uploaded as (current, next))."""
-        self.info = dict(static_track_optical_flow=0, static_track_detections=0, new_static_detections=False)
+        self.info = dict(static_track_optical_flow=0, static_track_detections=0, new_static_detections=False, static_track_ransac_rejected=0)
         if previous is None or len(previous) == 0:
             out = self.detect_features(frame_slot, motion_mask_cur, StaticFeatures(), detection_mask)
             self.info["static_track_detections"] = len(out)
             return out, np.zeros(0, np.int64)
         r = self.t.track_points_klt(previous.kp.astype(np.float32), init_pts)
         good = r["status"] == 1
+        if self.p.geometric_verification and good.any():
+            # geometricVerification (StaticFeatureTracker.cc:551-563, 627-640): RANSAC homography over the KLT survivors; the
+            # rejected ones join the outliers (determineOutlierIds takes the set difference with the VERIFIED tracklets, :600-603)
+            gi = np.nonzero(good)[0]
+            inl, _H, _best = self.t.verify_homography(previous.kp[gi].astype(np.float32), r["cur"][gi], self.p.ransac_threshold)
+            good[gi[~inl]] = False
+            self.info["static_track_ransac_rejected"] = int((~inl).sum())
         outliers = previous.tracklet_id[~good]
         kp = r["cur"].astype(np.float64)
         keep = good & self._usable(kp, motion_mask_cur) & (previous.age + 1 <= self.p.max_feature_track_age)

@@ -592,6 +592,16 @@ __global__ __launch_bounds__(FUSE_THREADS) void k_lin_error_fused(FusedBlocks F,
 }
 
 // deterministic sum of `ncol` interleaved columns: out[c] = sum_i in[i*ncol + c]; single block
+// out[f0 + i] = 0.5 |b_i|^2 of the linearised records of one factor block (the constant of a marginal)
+__global__ void k_half_b2(const double* __restrict__ J, int64_t rec0, int rec, int b_off, int dim, int64_t count, double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const double* r = J + rec0 + i * rec + b_off;
+  double s = 0.0;
+  for (int a = 0; a < dim; ++a) s += 0.5 * r[a] * r[a];
+  out[i] = s;
+}
+
 __global__ __launch_bounds__(1024) void k_reduce(const double* __restrict__ in, int64_t n, int ncol, double* __restrict__ out) {
   __shared__ double sh[1024];
   for (int c = 0; c < ncol; ++c) {

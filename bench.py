@@ -203,6 +203,10 @@ def main():
                                          "speculative_queued": int(rep.spec_queued), "speculative_used": int(rep.spec_used)}},
             "roofline": roof,
             "kernels": [{"name": s["name"], "launches": s["launches"], "total_ms": round(s["total_ms"], 3)} for s in stats],
+            "kernels_note": "HIP-event time per launch group on the stream it ran on; up to three solves (the candidate GTSAM tries and the speculative "
+                            "next ones) run concurrently on their own streams, so the rows add up to more than the timed region - the additive per-kernel "
+                            "table of the serialised run is profiles/r02_kernel_stats.txt (rocprofv3), the share of discarded speculative solves is "
+                            "config.lambda_search",
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(g, base_factors)

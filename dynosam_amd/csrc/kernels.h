@@ -788,6 +788,23 @@ __global__ void k_chain_factor(ChainView V, PointView P, const double* const* __
 // forward recursion  Y_i = L_ii^-1 (W_i^T - B_i Y_{i-1}).  Z blocks (6x3 = Y_i^T) are written for the positions
 // first..last of the edge as consecutive "sub-edges", so that assembly / rhs / back-substitution see a chain edge as
 // a run of ordinary pose-point edges:  W H_gg^-1 W'^T = sum_i Z_i Z'_i^T.
+// A pose-like neighbour of an eliminated point is a pose (Jacobian block 3x6) or a Point3 KEPT in the reduced system (a 6-wide
+// pseudo-pose whose block is 3x3: columns 3..5 are zero).  The width rides in bit 62 of the block's offset.
+constexpr int64_t JC_W3 = 1ll << 62;
+__device__ __forceinline__ void load_jc(const double* __restrict__ Jbuf, int64_t jc, double* __restrict__ out /*18: 3x6 row-major*/) {
+  if (jc & JC_W3) {
+    const double* p = Jbuf + (jc & ~JC_W3);
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) out[r * 6 + j] = j < 3 ? p[r * 3 + j] : 0.0;
+  } else {
+    const double* p = Jbuf + jc;
+#pragma unroll
+    for (int k = 0; k < 18; ++k) out[k] = p[k];
+  }
+}
+
 struct ChainEdgeView {
   int64_t n_cedge;
   const int32_t* ce_ptr;     // [n_cedge+1] contributions
@@ -817,7 +834,8 @@ __global__ void k_chain_edge(ChainEdgeView E, const int32_t* __restrict__ ch_poi
 #pragma unroll
     for (int t = 0; t < 18; ++t) Wt[t] = 0.0;
     for (; k < kend && E.ce_pos[k] == pos; ++k) {
-      const double* Jc = Jbuf + E.ce_jc[k];
+      double Jc[18];
+      load_jc(Jbuf, E.ce_jc[k], Jc);
       const double* Jp = Jbuf + E.ce_jp[k];
 #pragma unroll
       for (int r = 0; r < 3; ++r)
@@ -892,7 +910,8 @@ __global__ void k_edge_z(EdgeView E, const double* const* __restrict__ Jpp, cons
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E.n_edge || E.e_jc[e] < 0) return;   // e_jc < 0: sub-edge of a point chain, written by k_chain_edge
   const double* __restrict__ Jbuf = *Jpp;
-  const double* Jc = Jbuf + E.e_jc[e];
+  double Jc[18];
+  load_jc(Jbuf, E.e_jc[e], Jc);
   const double* Jp = Jbuf + E.e_jp[e];
   const double* C = Cq + 6 * (int64_t)E.e_point[e];
   double M[9];  // Jp * C (C upper triangular)

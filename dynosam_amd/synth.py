@@ -494,8 +494,14 @@ def make_wcme_graph(cfg: ScenarioConfig) -> FlatGraph:
     for b in blocks:
         out.append(FactorBlock(b.type, np.arange(s0, s0 + b.count), b.var_idx, b.meas, b.noise, b.huber_k, b.consts))
         s0 += b.count
+    # frame of insertion of every variable (H_{j,k}: k; X_k: k; static landmark: first observation; m_{i,k}: k) and of every factor
+    # (the latest frame among its variables) - what a frame stream / a sliding window splits the batch graph by
+    H_frame = np.array([k for _j in range(J) for k in range(1, K)], dtype=np.int64)
+    var_frame_all = np.concatenate([H_frame, np.arange(K), s_birth, do_frame]).astype(np.int64)
+    var_frame = var_frame_all[order]
+    factor_frame = [var_frame[b.var_idx].max(axis=1) for b in out]
     return FlatGraph(all_keys[order], all_type[order], all_state[order], out,
-                     dict(cfg=cfg, gt_state=gt_state[order], frames=K, objects=J, obj_xi=obj_xi, L0=L0))
+                     dict(cfg=cfg, gt_state=gt_state[order], frames=K, objects=J, obj_xi=obj_xi, L0=L0, var_frame=var_frame, factor_frame=factor_frame))
 
 
 def make_wcpe_graph(cfg: ScenarioConfig) -> FlatGraph:

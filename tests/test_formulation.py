@@ -202,6 +202,43 @@ def test_backend_loop_formulation_plus_sliding_window_on_the_gpu():
     sw.ctx.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["wcme", "wcpe"])
+def test_backend_loop_world_centric_formulations_plus_sliding_window_on_the_gpu(kind):
+    """the same backend loop with the world-centric formulations: their per-frame points form chains that every window cuts, so
+    the marginal names chain points that stay coupled (ternary / LandmarkMotionPose factors) with the next, still eliminated ones"""
+    from dynosam_amd._lib import IndeterminantLinearSystemException
+    from dynosam_amd.sliding_window import NativeSlidingWindowOptimization
+    from dynosam_amd.synth import se3_exp
+    pk, _ = make_stream(n_frames=16, seed=4)
+    rng = np.random.default_rng(6)
+    for p in pk[1:]:
+        p.X_world = to12(compose(from12(p.X_world), se3_exp(np.concatenate([rng.normal(0, 0.002, 3), rng.normal(0, 0.02, 3)]))))
+        p.static[:, 1:] += rng.normal(0, 0.01, p.static[:, 1:].shape)
+        p.dynamic[:, 2:] += rng.normal(0, 0.01, p.dynamic[:, 2:].shape)
+    wf = F.WorldMotionFormulation() if kind == "wcme" else F.WorldPoseFormulation()
+    sw = NativeSlidingWindowOptimization(window_size=6, overlap=3)
+    n_opt = 0
+    for p in pk:
+        span = wf.update(p)
+        vals, blocks = wf.new_values_and_factors(span)
+        try:
+            r = sw.update(blocks, vals, p.frame_id)
+        except IndeterminantLinearSystemException:
+            # WCPE has no prior on the object poses (WorldPoseEstimator.cc adds none): once fewer than three points of the object
+            # remain in the frames being marginalised the eliminated block is singular - the oracle's dense elimination fails on
+            # the same window (scripts/dbg_wcpe_window.py), GTSAM's EliminatePreferCholesky throws this exception there
+            assert kind == "wcpe" and n_opt >= 2
+            break
+        if r.optimized:
+            n_opt += 1
+            assert r.report.error_after < r.report.error_before
+            keys, _vt, st = sw.result_values()
+            wf.set_values([int(k) for k in keys], list(st))
+    assert n_opt >= (3 if kind == "wcme" else 2)
+    sw.close(); sw.ctx.close()
+
+
 # ---- world-centric formulations and the stereo static updater (SURVEY.md 8f row 1, widened) ----
 def test_wcme_builder_exact_data_zero_error_and_structure(oracle):
     pk, info = make_stream()

@@ -648,13 +648,21 @@ struct PointView {
 };
 
 // C = L^-T (upper, 6 values: c00 c01 c02 c11 c12 c22), u = L^-1 g
+// gtsam::LevenbergMarquardtParams::diagonalDamping: lambda_p[1] != 0 -> the damping of a scalar is lambda * clip(H_ii, 1e-6, 1e32),
+// H_ii the diagonal of the UN-reduced J^T J (LevenbergMarquardtOptimizer::iterate / buildDampedSystem), else lambda.
+__device__ __forceinline__ double lm_damp(double lambda, bool diag, double hii) {
+  return diag ? lambda * fmin(fmax(hii, 1e-6), 1e32) : lambda;
+}
+
 __global__ void k_point(PointView P, const double* const* __restrict__ Jpp, const double* __restrict__ lambda_p,
                         double* __restrict__ Cq, double* __restrict__ uq, int* __restrict__ fail_flag) {
   const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= P.n_point || (P.chained && P.chained[q])) return;
   const double* __restrict__ Jbuf = *Jpp;
   const double lambda = *lambda_p;
-  double h00 = lambda, h01 = 0, h02 = 0, h11 = lambda, h12 = 0, h22 = lambda, g0 = 0, g1 = 0, g2 = 0;
+  const bool ddamp = lambda_p[1] != 0.0;
+  const double l0 = ddamp ? 0.0 : lambda;        // (identity damping goes in first, as it always did: same rounding as before)
+  double h00 = l0, h01 = 0, h02 = 0, h11 = l0, h12 = 0, h22 = l0, g0 = 0, g1 = 0, g2 = 0;
   for (int k = P.pf_ptr[q]; k < P.pf_ptr[q + 1]; ++k) {
     const double* J = Jbuf + P.pf_joff[k];
     const double* b = Jbuf + P.pf_boff[k];
@@ -665,6 +673,7 @@ __global__ void k_point(PointView P, const double* const* __restrict__ Jpp, cons
       g0 += a0 * br; g1 += a1 * br; g2 += a2 * br;
     }
   }
+  if (ddamp) { h00 += lm_damp(lambda, true, h00); h11 += lm_damp(lambda, true, h11); h22 += lm_damp(lambda, true, h22); }
   // Cholesky H = L L^T
   bool ok = h00 > 0.0;
   const double l00 = sqrt(ok ? h00 : 1.0);
@@ -714,10 +723,12 @@ __global__ void k_chain_factor(ChainView V, PointView P, const double* const* __
   if (g >= V.n_chain) return;
   const double* __restrict__ Jbuf = *Jpp;
   const double lambda = *lambda_p;
+  const bool ddamp = lambda_p[1] != 0.0;
+  const double l0 = ddamp ? 0.0 : lambda;
   double Cp[6] = {0, 0, 0, 0, 0, 0}, up[3] = {0, 0, 0};   // previous position: C = L^-T (upper), u
   for (int pos = V.ch_ptr[g]; pos < V.ch_ptr[g + 1]; ++pos) {
     const int64_t q = V.ch_point[pos];
-    double h[6] = {lambda, 0, 0, lambda, 0, lambda}, gq[3] = {0, 0, 0};   // h00 h01 h02 h11 h12 h22
+    double h[6] = {l0, 0, 0, l0, 0, l0}, gq[3] = {0, 0, 0};   // h00 h01 h02 h11 h12 h22
     for (int k = P.pf_ptr[q]; k < P.pf_ptr[q + 1]; ++k) {
       const double* J = Jbuf + P.pf_joff[k];
       const double* b = Jbuf + P.pf_boff[k];
@@ -728,6 +739,7 @@ __global__ void k_chain_factor(ChainView V, PointView P, const double* const* __
         gq[0] += a0 * br; gq[1] += a1 * br; gq[2] += a2 * br;
       }
     }
+    if (ddamp) { h[0] += lm_damp(lambda, true, h[0]); h[3] += lm_damp(lambda, true, h[3]); h[5] += lm_damp(lambda, true, h[5]); }
     double B[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (pos > V.ch_ptr[g]) {
       // O^T = sum J_later^T J_earlier  (rows: this point, columns: previous point)
@@ -1104,8 +1116,15 @@ __global__ void k_assemble_final_tiles(AssembleView A, const double* __restrict_
   const int i = el / 6, j = el % 6;
   const int a = A.blk_a[blk], b = A.blk_b[blk];
   if (a == b && j > i) return;
-  double acc = (a == b && i == j) ? add_lambda * (*lambda_p) : 0.0;
-  for (int c = A.blk_ch[blk]; c < A.blk_ch[blk + 1]; ++c) acc += partial[(int64_t)c * 36 + el];
+  const bool dg = a == b && i == j, ddamp = lambda_p[1] != 0.0;
+  double acc = (dg && !ddamp) ? add_lambda * (*lambda_p) : 0.0;
+  double raw = 0.0;   // diagonal of the un-reduced J^T J: the DIRECT contributions of the block (factors and the dense prior), not the Schur pairs
+  for (int c = A.blk_ch[blk]; c < A.blk_ch[blk + 1]; ++c) {
+    const double v = partial[(int64_t)c * 36 + el];
+    acc += v;
+    if (A.ch_kind[c] == 1) raw += v;
+  }
+  if (dg && ddamp) acc += add_lambda * lm_damp(*lambda_p, true, raw);
   const int oa = off[a], ob = off[b];
   int gi = oa + i, gj = ob + j;
   if (oa < ob) { const int tmp = gi; gi = gj; gj = tmp; }

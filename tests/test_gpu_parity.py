@@ -292,6 +292,30 @@ def test_lazy_graph_capture_in_the_middle_of_a_search_changes_nothing(lib_loaded
     assert np.array_equal(v1, c2.values())
 
 
+@pytest.mark.parametrize("kind", ["hybrid", "wcme"])
+def test_diagonal_damping_follows_the_oracle(lib_loaded, kind):
+    """gtsam::LevenbergMarquardtParams::diagonalDamping = true: lambda diag(clip(diag(J^T J), 1e-6, 1e32)) instead of lambda I, the
+    diagonal of the UN-reduced system (points: their own 3x3 block; pose-like variables: the direct contributions of their diagonal
+    block, not the Schur complement).  Same accept / reject trace, iteration counts and final cost as the oracle."""
+    from dynosam_amd.optimizer import LevenbergMarquardtParams
+    from oracle import oracle_py as O
+    g = small(frames=14, static_points=80, dynamic_points_per_object=24, seed=12) if kind == "hybrid" else wcme(frames=10, seed=3)
+    P = LevenbergMarquardtParams()
+    P.diagonal_damping = 1
+    c = ctx_for(g)
+    r = c.optimize(P)
+    og = O.OracleGraph(g)
+    rr, _ = og.optimize(P)
+    assert (r.iterations, r.inner_iterations) == (rr.iterations, rr.inner_iterations)
+    assert [bool(r.trace_accepted[i]) for i in range(r.trace_len)] == [bool(rr.trace_accepted[i]) for i in range(rr.trace_len)]
+    assert abs(r.error_after - rr.error_after) <= 1e-6 * max(rr.error_after, 1e-12)
+    assert np.abs(c.values() - og.state()).max() <= 1e-5
+    # and it is a different search from identity damping
+    c.set_values(g.var_state)
+    r0 = c.optimize()
+    assert [r0.trace_error[i] for i in range(r0.trace_len)] != [r.trace_error[i] for i in range(r.trace_len)]
+
+
 def test_values_roundtrip_and_reupload(lib_loaded):
     g = small()
     c = ctx_for(g)

@@ -100,3 +100,21 @@ def test_new_factor_classes_analytic_vs_numeric_jacobians(oracle):
                 em, _ = oracle.eval_factor(ftype, sm, meas, consts, want_J=False)
                 num = (ep[:dim] - em[:dim]) / 2e-6
                 assert np.abs(J[:dim, 6 * s + j] - num).max() <= 2e-5 * max(1.0, np.abs(num).max()), (ftype, s, j)
+
+
+def test_diagonal_damping_dense_equals_schur_and_changes_the_search():
+    """gtsam diagonalDamping in the oracle: lambda diag(clip(diag(J^T J))) - the dense and the Schur path damp the same (un-reduced)
+    diagonal, and the search differs from identity damping"""
+    from dynosam_amd import synth
+    from oracle import oracle_py as O
+    g = synth.make_hybrid_graph(synth.config(1, frames=12, static_points=60, dynamic_points_per_object=20))
+    out = {}
+    for dense in (False, True):
+        for dd in (0, 1):
+            og = O.OracleGraph(g); og.set_dense(dense)
+            P = O.default_params(); P.diagonal_damping = dd
+            r, _ = og.optimize(P)
+            out[dense, dd] = (r.iterations, r.inner_iterations, r.error_after)
+    assert out[False, 1][:2] == out[True, 1][:2] and abs(out[False, 1][2] - out[True, 1][2]) <= 1e-9 * out[True, 1][2]
+    assert out[False, 0][:2] == out[True, 0][:2]
+    assert out[False, 1][2] != out[False, 0][2]

@@ -69,3 +69,65 @@ def test_static_tracker_drops_what_the_verification_rejects(tracker, monkeypatch
     kt.p.geometric_verification = False
     cur2, outliers2 = kt.track_static(first, sc["mask1"])
     assert set(tampered.ids.tolist()) & set(cur2.tracklet_id.tolist())
+
+
+def test_stereo_track_on_a_shifted_pair_matches_the_oracle(tracker):
+    """FeatureTracker::stereoTrack: right image = left image shifted by a constant disparity D.  LK recovers the shift, the epipolar
+    RANSAC keeps the matches, depth = fx b / D; codes, depths and F equal the oracle's bit for bit on the device's LK output;
+    (a constant disparity is a degenerate configuration for the seven-point model - planted geometry is in the next test)."""
+    from dynosam_amd import synth_images as SI
+    D, fx, b = 9, 700.0, 0.12
+    sc = SI.make_pair(640, 480, objects=0, seed=5)
+    left = sc["rgb0"]
+    right = np.roll(left, -D, axis=1)
+    zero = np.zeros_like(sc["mask0"])
+    tracker.upload(left, zero, right, zero)
+    pts = tracker.detect_corners(0, None, 400)
+    pts = pts[(pts[:, 0] > 40) & (pts[:, 0] < 600) & (pts[:, 1] > 30) & (pts[:, 1] < 450)][:240]
+    r = tracker.stereo_track(pts, fx, b)
+    assert r["ok"] == 1 and r["n_klt"] >= 200
+    ok = r["code"] == 0
+    assert ok.sum() >= 170
+    assert np.abs((pts[ok, 0] - r["right"][ok, 0]) - D).max() < 0.05 and np.abs(pts[ok, 1] - r["right"][ok, 1]).max() < 0.05
+    assert np.abs(r["depth"][ok] - fx * b / D).max() < 0.06
+    ref = RO.stereo_track(pts, r["right"], r["code"] != 1, fx, b)
+    assert ref["ok"] == 1 and np.array_equal(ref["code"], r["code"]) and np.array_equal(ref["depth"], r["depth"])
+    assert np.array_equal(ref["F"], r["F"].reshape(9))
+    assert tracker.stereo_track(pts[:5], fx, b)["ok"] == 0                                   # fewer than 8 points: the reference returns false
+
+
+def test_stereo_ransac_on_planted_matches(tracker):
+    """general geometry (per-point disparity from random depths, 0.15 px noise) with 25 matches dragged off their epipolar lines, handed
+    to the device as the matcher's output: outliers get code 2, the rest depth = fx b / disparity; bit-identical to the oracle."""
+    from test_ransac_oracle import planted_stereo
+    left, right, out, z = planted_stereo()
+    st = np.ones(len(left), np.uint8); st[:3] = 0
+    r = tracker.stereo_track(left, 700.0, 0.12, matches=(right, st))
+    ref = RO.stereo_track(left, right, st, 700.0, 0.12)
+    assert r["ok"] == 1 and np.array_equal(r["code"], ref["code"]) and np.array_equal(r["depth"], ref["depth"]) and np.array_equal(r["F"].reshape(9), ref["F"])
+    assert (r["code"][:3] == 1).all()
+    keep = np.setdiff1d(np.arange(3, len(left)), out)
+    assert (r["code"][np.setdiff1d(out, [0, 1, 2])] == 2).all() and (r["code"][keep] == 0).mean() > 0.9
+    good = r["code"] == 0
+    assert np.median(np.abs(r["depth"][good] - z[good]) / z[good]) < 0.05
+
+
+def test_feature_tracker_stereo_track_mirror():
+    """FeatureTracker.stereo_track: the reference's outputs - stereo features with depth and right keypoint, everything else an outlier"""
+    from dynosam_amd import synth_images as SI
+    from dynosam_amd.feature_tracker import FeatureTracker
+    from dynosam_amd.static_tracker import StaticFeatures
+    D, fx, b = 7, 700.0, 0.12
+    sc = SI.make_pair(640, 480, objects=0, seed=8)
+    left = sc["rgb0"]; right = np.roll(left, -D, axis=1)
+    ft = FeatureTracker(640, 480)
+    ft.t.upload(left, np.zeros_like(sc["mask0"]), right, np.zeros_like(sc["mask0"]))
+    pts = ft.t.detect_corners(0, None, 300)
+    pts = pts[(pts[:, 0] > 40) & (pts[:, 0] < 600) & (pts[:, 1] > 30) & (pts[:, 1] < 450)][:150]
+    st = StaticFeatures(np.arange(len(pts)) + 1000, pts.astype(np.float64), np.zeros(len(pts), np.int64))
+    r = ft.stereo_track(st, left, right, fx, b)
+    assert r is not None and r["stereo"].sum() >= 130
+    assert np.abs(r["depth"][r["stereo"]] - fx * b / D).max() < 0.1
+    assert np.array_equal(r["right_kp"][:, 1], st.kp[:, 1])
+    assert set(r["outlier_ids"].tolist()) == set(st.tracklet_id[~r["stereo"]].tolist())
+    assert ft.stereo_track(StaticFeatures(st.tracklet_id[:5], st.kp[:5], st.age[:5]), left, right, fx, b) is None

@@ -43,3 +43,47 @@ def test_degenerate_inputs():
     line = np.c_[np.arange(10), np.arange(10)].astype(np.float32)
     mask, best, _H = RO.verify_homography(line, line + 1)               # every sample collinear: no valid hypothesis
     assert best == -1 and mask.sum() == 0
+
+
+def planted_stereo(n=160, n_out=25, seed=0, noise=0.15):
+    """rectified pair: right = left shifted by a positive disparity along x (fx b / z), same row; outliers moved off their rows"""
+    rng = np.random.default_rng(seed)
+    left = rng.uniform([30, 30], [610, 450], (n, 2))
+    z = rng.uniform(2.0, 30.0, n)
+    disp = 700.0 * 0.12 / z
+    right = left.copy(); right[:, 0] -= disp
+    right += rng.normal(0, noise, (n, 2))
+    out = rng.choice(n, n_out, replace=False)
+    right[out, 1] += rng.uniform(4, 30, n_out) * rng.choice([-1, 1], n_out)
+    return left.astype(np.float32), right.astype(np.float32), out, z
+
+
+def test_cubic_roots_bracketing():
+    for roots in ([-2.0, 0.5, 3.0], [1.0, 1.0, 4.0], [-0.3]):
+        if len(roots) == 3:
+            c = np.poly(roots)          # t^3 + ...
+            c3, c2, c1, c0 = c
+        else:
+            c3, c2, c1, c0 = 1.0, 0.3 + 0.0, 1.0 + 0.3 * 0.0, 0.3        # (t + 0.3)(t^2 + 1)
+        got = RO.cubic_roots(c0, c1, c2, c3)
+        for r in got:
+            assert abs(((c3 * r + c2) * r + c1) * r + c0) < 1e-9
+        assert len(got) >= 1
+
+
+def test_seven_point_models_contain_the_true_geometry():
+    left, right, _out, _z = planted_stereo(n=7, n_out=0, noise=0.0, seed=3)
+    Fs = RO.seven_point(left, right)
+    assert len(Fs) >= 1
+    assert min(RO.fm_error(F, left, right).max() for F in Fs) < 1e-6
+
+
+def test_fundamental_ransac_rejects_planted_row_outliers():
+    left, right, out, _z = planted_stereo()
+    mask, best, _F = RO.find_fundamental(left, right, 1.0)
+    assert best >= 0 and mask[out].sum() == 0 and mask.sum() >= 0.9 * (len(left) - len(out))
+    r = RO.stereo_track(left, right, np.ones(len(left), np.uint8), 700.0, 0.12)
+    assert r["ok"] == 1 and (r["code"][out] == 2).all() and r["n_stereo"] == int((r["code"] == 0).sum()) > 100
+    ok = r["code"] == 0
+    assert np.all(r["depth"][ok] > 1.5) and np.all(r["depth"][ok] < 40.0)
+    assert RO.stereo_track(left[:5], right[:5], np.ones(5, np.uint8), 700.0, 0.12)["ok"] == 0       # fewer than 8 points

@@ -132,9 +132,13 @@ class Context:
         prior = None
         if m.prior.n_keys > 0:
             nk, dim = m.prior.n_keys, m.prior.dim
-            prior = LinearPrior(np.ctypeslib.as_array(m.prior.keys, (nk,)).copy(), np.ctypeslib.as_array(m.prior.lin_state, (nk * 12,)).copy().reshape(nk, 12),
-                                np.ctypeslib.as_array(m.prior.Lambda, (dim * dim,)).copy().reshape(dim, dim),
-                                np.ctypeslib.as_array(m.prior.eta, (dim,)).copy(), float(m.prior.c))
+            keys_ = np.ctypeslib.as_array(m.prior.keys, (nk,)).copy()
+            lin_ = np.ctypeslib.as_array(m.prior.lin_state, (nk * 12,)).copy().reshape(nk, 12)
+            if not m.prior.Lambda:     # sharded context, not the rank that carries the values: structure only (include/dynogfx.h)
+                prior = LinearPrior(keys_, lin_, None, None, 0.0)
+            else:
+                prior = LinearPrior(keys_, lin_, np.ctypeslib.as_array(m.prior.Lambda, (dim * dim,)).copy().reshape(dim, dim),
+                                    np.ctypeslib.as_array(m.prior.eta, (dim,)).copy(), float(m.prior.c))
         return blocks, prior
 
     def set_profiling(self, on: bool):

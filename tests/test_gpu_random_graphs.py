@@ -62,3 +62,40 @@ def test_random_graph_follows_the_oracle(case):
             assert np.abs(prior.Lambda - rp.Lambda).max() <= 1e-7 * max(1.0, np.abs(rp.Lambda).max()), (kw, cut)
             assert np.abs(prior.eta - rp.eta).max() <= 1e-7 * max(1.0, np.abs(rp.eta).max()), (kw, cut)
     c.close()
+
+
+@pytest.mark.parametrize("case", range(8))
+def test_random_graph_sharded_equals_single_context(case):
+    """the sharded path on random trajectories (hybrid / WCME, 2-4 in-process ranks): damped solve and LM trace of every rank equal the
+    single-context solve; replicated values bitwise equal across ranks (short windows fall back to the replicated solve)"""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_gpu_multirank import run_ranks
+    from dynosam_amd.optimizer import Context
+    rng = np.random.default_rng(2000 + case)
+    frames = int(rng.integers(24, 90))
+    kw = dict(frames=frames, objects=int(rng.integers(1, 3)), static_points=int(frames * rng.integers(2, 6)),
+              dynamic_points_per_object=int(frames * rng.uniform(0.5, 1.5)), seed=int(rng.integers(0, 10_000)))
+    world = int(rng.integers(2, 5))
+    g = (synth.make_wcme_graph if case % 2 else synth.make_hybrid_graph)(synth.config(1, **kw))
+    c = Context(); c.upload(g)
+    lam = float(10.0 ** rng.integers(-5, -1))
+    d_ref, dec_ref = c.solve_damped(lam)
+    r0 = c.optimize()
+    v0 = c.values()
+
+    def work(ctx):
+        d = ctx.solve_damped(lam)
+        ctx.set_values(g.var_state)
+        r = ctx.optimize()
+        return d, r, ctx.values()
+
+    res = run_ranks(g, world, work)
+    for (d, dec), r, v in res:
+        assert np.abs(d - d_ref).max() <= 1e-6 * max(1.0, np.abs(d_ref).max()) and abs(dec - dec_ref) <= 1e-6 * abs(dec_ref), (kw, world)
+        assert (r.iterations, r.inner_iterations) == (r0.iterations, r0.inner_iterations), (kw, world)
+        assert abs(r.error_after - r0.error_after) <= 1e-6 * max(r0.error_after, 1e-9)
+        assert np.abs(v - v0).max() <= 1e-5
+    for _d, _r, v in res[1:]:
+        assert np.array_equal(v, res[0][2])
+    c.close()

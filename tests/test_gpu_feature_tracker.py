@@ -100,3 +100,20 @@ def test_native_tracker_equals_the_python_composition(short_lives):
         sa, sb = fa.info["static"], fb.info["static"]
         assert all(int(sa[kk]) == int(sb[kk]) for kk in ("static_track_optical_flow", "static_track_detections", "new_static_detections", "static_track_ransac_rejected"))
     a.close(); b.close()
+
+
+def test_native_tracker_rejects_a_gap_in_the_frame_ids_and_survives_missing_next_mask():
+    """FeatureTracker::track CHECKs consecutive frame ids; a missing `motion_mask_next` only costs the mask re-upload of the next call"""
+    from dynosam_amd._lib import DynoError
+    from dynosam_amd.feature_tracker import NativeFeatureTracker
+    rgb, mask = SI.make_sequence(640, 480, objects=2, frames=5, seed=23)
+    a, b = NativeFeatureTracker(640, 480), NativeFeatureTracker(640, 480)
+    fa0 = a.track(0, 0.0, rgb[0], mask[0], rgb[1], mask[1])
+    fb0 = b.track(0, 0.0, rgb[0], mask[0], rgb[1], None)            # next mask not given: frame 1's mask is passed (and uploaded) with frame 1
+    assert np.array_equal(fa0.static.kp, fb0.static.kp)
+    fa1 = a.track(1, 0.1, rgb[1], mask[1], rgb[2], mask[2])
+    fb1 = b.track(1, 0.1, rgb[1], mask[1], rgb[2], mask[2])
+    assert fa1.objects == fb1.objects and np.array_equal(fa1.static.kp, fb1.static.kp) and np.array_equal(fa1.static.tracklet_id, fb1.static.tracklet_id)
+    with pytest.raises(DynoError):
+        a.track(3, 0.3, rgb[3], mask[3], rgb[4], mask[4])
+    a.close(); b.close()

@@ -98,6 +98,9 @@ class SlidingWindowOptimization:
             self.key_frame[int(k)] = frame_id
         self.current_frame = frame_id
         self.blocks += list(new_blocks)
+        dup = [int(k) for k in new_values if int(k) in self.values]
+        if dup:       # values_.insert(new_values): gtsam::ValuesKeyAlreadyExists (SlidingWindowOptimization.cc:52)
+            raise KeyError(f"gtsam::ValuesKeyAlreadyExists: {dup[0]}")
         self.values.update({int(k): v for k, v in new_values.items()})
         self.frame_window.append(frame_id)
         if len(self.frame_window) > self.window_size:

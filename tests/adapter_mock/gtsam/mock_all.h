@@ -75,6 +75,7 @@ class Values {
   std::map<Key, std::shared_ptr<Value>> m;
 };
 struct ValuesKeyDoesNotExist : std::exception { ValuesKeyDoesNotExist(const char*, Key) {} };
+struct ValuesKeyAlreadyExists : std::exception { explicit ValuesKeyAlreadyExists(Key) {} };   // gtsam/nonlinear/Values.h
 struct IndeterminantLinearSystemException : std::exception { Key j; explicit IndeterminantLinearSystemException(Key k) : j(k) {} Key nearbyVariable() const { return j; } };
 
 namespace noiseModel {

@@ -267,7 +267,8 @@ import ctypes as _C  # noqa: E402
 
 
 class _TrkParams(_C.Structure):
-    _fields_ = [("max_nr_keypoints_before_anms", _C.c_int32), ("min_static", _C.c_int32), ("min_dynamic", _C.c_int32), ("max_features_per_frame", _C.c_int32),
+    _fields_ = [("max_nr_keypoints_before_anms", _C.c_int32), ("min_distance_btw_tracked_and_detected_static_features", _C.c_int32),
+                ("min_distance_btw_tracked_and_detected_dynamic_features", _C.c_int32), ("max_features_per_frame", _C.c_int32),
                 ("min_features_per_frame", _C.c_int32), ("max_feature_track_age", _C.c_int32), ("shrink_row", _C.c_int32), ("shrink_col", _C.c_int32),
                 ("quality_level", _C.c_double), ("use_anms", _C.c_int32), ("geometric_verification", _C.c_int32), ("ransac_threshold", _C.c_double),
                 ("max_dynamic_features_per_frame", _C.c_int32), ("max_dynamic_feature_age", _C.c_int32), ("dynamic_feature_age_buffer", _C.c_int32),

@@ -882,28 +882,33 @@ __global__ void k_gather_x(const double* __restrict__ X, const int32_t* __restri
   if (o >= 0 && (write_sep || dkind[o] != 2)) v = X[o + (int)(i % 6)];
   dpose[i] = v;
 }
+// lambda, or gtsam's diagonalDamping lambda*clip(h, 1e-6, 1e32) of the un-reduced Hessian diagonal h when lambda_p[1] != 0 (kernels.h: lm_damp)
+__device__ __forceinline__ double tile_damp(const double* __restrict__ lambda_p, double h) {
+  return lambda_p[1] != 0.0 ? lambda_p[0] * fmin(fmax(h, 1e-6), 1e32) : lambda_p[0];
+}
 // diagonal of the tiled matrix. Row kinds: 0 real, 1 padding, 2 real row of the part summed over ranks, 3 padding there.
 // pass 0 (before the factorisation): kind 1 := 1, kind 0 += scale*lambda;   pass 1 (after the all-reduce): kind 3 := 1, kind 2 += scale*lambda
 __global__ void k_tile_diag(double* __restrict__ A, const int32_t* __restrict__ diag_tile, const uint8_t* __restrict__ dkind, int npad,
-                            const double* __restrict__ lambda_p, double scale, int pass) {
+                            const double* __restrict__ lambda_p, double scale, int pass, const double* __restrict__ raw) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= npad) return;
   double* p = A + (int64_t)diag_tile[i / CT_TS] * CT_TT + (i % CT_TS) * (CT_TS + 1);
   const int k = dkind[i];
   if (k == (pass ? 3 : 1)) *p = 1.0;
-  else if (k == (pass ? 2 : 0) && scale != 0.0) *p += scale * (*lambda_p);
+  else if (k == (pass ? 2 : 0) && scale != 0.0) *p += scale * tile_damp(lambda_p, raw[i]);
 }
 
 // k_tile_diag (pass 0) and k_scatter_rhs in one launch
 __global__ void k_diag_rhs(double* __restrict__ A, const int32_t* __restrict__ diag_tile, const uint8_t* __restrict__ dkind, int npad,
-                           const double* __restrict__ lambda_p, double scale, const double* __restrict__ gc, const int32_t* __restrict__ off,
+                           const double* __restrict__ lambda_p, double scale, const double* __restrict__ raw, const double* __restrict__ gc,
+                           const int32_t* __restrict__ off,
                            int64_t n_pose, double* __restrict__ rhs) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < npad) {
     double* p = A + (int64_t)diag_tile[i / CT_TS] * CT_TT + (i % CT_TS) * (CT_TS + 1);
     const int k = dkind[i];
     if (k == 1) *p = 1.0;
-    else if (k == 0 && scale != 0.0) *p += scale * (*lambda_p);
+    else if (k == 0 && scale != 0.0) *p += scale * tile_damp(lambda_p, raw[i]);
   }
   if (i < 6 * n_pose) {
     const int32_t o = off[i / 6];

@@ -1135,7 +1135,8 @@ __global__ void k_assemble_final(AssembleView A, const double* __restrict__ part
 // blk_tile[4 blk + ti + 2 tj] = tile id of tile (R0/TS + ti, C0/TS + tj), R0 = max(off), C0 = min(off).
 __global__ void k_assemble_final_tiles(AssembleView A, const double* __restrict__ partial, const double* __restrict__ lambda_p,
                                        double add_lambda, const int32_t* __restrict__ off, const int32_t* __restrict__ blk_tile,
-                                       double* __restrict__ At) {
+                                       double* __restrict__ At, double* __restrict__ raw_int = nullptr, double* __restrict__ raw_sep = nullptr,
+                                       int raw_split = 0) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t blk = t / 36;
   const int el = (int)(t % 36);
@@ -1153,6 +1154,9 @@ __global__ void k_assemble_final_tiles(AssembleView A, const double* __restrict_
   }
   if (dg && ddamp) acc += add_lambda * lm_damp(*lambda_p, true, raw);
   const int oa = off[a], ob = off[b];
+  // sharded path: the damping is added later (k_diag_rhs for this rank's interior rows, k_tile_diag after the all-reduce for the
+  // separator rows, whose un-reduced diagonal is a sum over ranks and travels with the all-reduce)
+  if (dg && ddamp && raw_int) (oa + i >= raw_split ? raw_sep : raw_int)[oa + i] = raw;
   int gi = oa + i, gj = ob + j;
   if (oa < ob) { const int tmp = gi; gi = gj; gj = tmp; }
   const int R0 = oa > ob ? oa : ob, C0 = oa > ob ? ob : oa;

@@ -191,6 +191,42 @@ def test_sharded_wcme_graph_with_point_chains(world):
         assert np.array_equal(v, res[0][2])
 
 
+@pytest.mark.parametrize("world,kind", [(2, "hybrid"), (3, "hybrid"), (2, "wcme"), (2, "short")])
+def test_sharded_diagonal_damping_follows_the_single_context(world, kind):
+    """gtsam diagonalDamping on the sharded path: the un-reduced Hessian diagonal of a separator pose is a sum over ranks, so it
+    travels with the separator all-reduce and the damping of those rows is added after it; interior rows and points are damped
+    locally.  Same LM trace and values as the single context ("short": the replicated fallback, every row summed)."""
+    from dynosam_amd.optimizer import Context, LevenbergMarquardtParams
+    if kind == "hybrid":
+        g = graph()
+    elif kind == "short":
+        g = synth.make_hybrid_graph(synth.config(1, frames=24, static_points=120, dynamic_points_per_object=24, seed=3))
+    else:
+        g = synth.make_wcme_graph(synth.config(1, frames=90, objects=2, static_points=360, dynamic_points_per_object=60, seed=12))
+    P = LevenbergMarquardtParams()
+    P.diagonal_damping = 1
+    c = Context(); c.upload(g)
+    r0 = c.optimize(P)
+    v0 = c.values()
+    c.set_values(g.var_state)
+    ri = c.optimize()
+    assert [ri.trace_error[i] for i in range(ri.trace_len)] != [r0.trace_error[i] for i in range(r0.trace_len)]   # not identity damping
+
+    def work(ctx):
+        r = ctx.optimize(P)
+        return r, ctx.values()
+
+    res = run_ranks(g, world, work)
+    for r, v in res:
+        assert r.iterations == r0.iterations and r.inner_iterations == r0.inner_iterations
+        assert [r.trace_accepted[i] for i in range(r.trace_len)] == [r0.trace_accepted[i] for i in range(r0.trace_len)]
+        assert abs(r.error_after - r0.error_after) <= 1e-6 * r0.error_after
+        assert np.abs(v - v0).max() <= 1e-5
+    for _r, v in res[1:]:
+        assert np.array_equal(v, res[0][1])
+    c.close()
+
+
 def test_sharded_window_with_containers_and_a_prior_on_points():
     """a sliding-window graph on the sharded path: linear containers (ordinary factor blocks of the shard) and the dense
     Hessian-form prior - ONE factor, carried by rank 0, naming poses AND points (kept in rank 0's reduced system).  Built

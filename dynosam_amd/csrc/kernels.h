@@ -1002,6 +1002,9 @@ struct AssembleView {
 // product sits in the top-left corner of the 16x16 accumulator. Each lane loads ONE double per operand - the vector
 // memory pipeline, not arithmetic, bounds this kernel, and the scalar formulation issued 6 loads per contribution.
 // Fixed order => deterministic.
+#ifndef ASM_PAIR_U
+#define ASM_PAIR_U 4
+#endif
 __device__ __forceinline__ void asm_chunks_body(AssembleView A, const double* const* __restrict__ Jpp,
                                                 const double* __restrict__ Z, double* __restrict__ partial, const int bid, const int nblocks) {
   typedef double d4_t __attribute__((ext_vector_type(4)));
@@ -1027,11 +1030,11 @@ __device__ __forceinline__ void asm_chunks_body(AssembleView A, const double* co
     const int half = ij >> 3, r6 = ij & 7;
     const bool ld = r6 < 6 && g < 3;
     const int zo = ld ? 3 * r6 + g : 0;
-    // 4 MFMAs (8 contributions) per trip: their loads are independent and issue back to back
-    for (int k0 = 0; k0 < n; k0 += 8) {
-      double a[4], b[4];
+    // ASM_PAIR_U MFMAs (2 contributions each) per trip: their loads are independent and issue back to back
+    for (int k0 = 0; k0 < n; k0 += 2 * ASM_PAIR_U) {
+      double a[ASM_PAIR_U], b[ASM_PAIR_U];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < ASM_PAIR_U; ++u) {
         const int ka = k0 + 2 * u;   // lanes >= n hold row 0 (a valid address); masked below
         const int f1a = __builtin_amdgcn_readlane(e1, ka & 63), f2a = __builtin_amdgcn_readlane(e2, ka & 63);
         const int f1b = __builtin_amdgcn_readlane(e1, (ka + 1) & 63), f2b = __builtin_amdgcn_readlane(e2, (ka + 1) & 63);
@@ -1040,7 +1043,7 @@ __device__ __forceinline__ void asm_chunks_body(AssembleView A, const double* co
         if (ld && ka + half < n) { a[u] = -Z[18 * (int64_t)f1 + zo]; b[u] = Z[18 * (int64_t)f2 + zo]; }
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+      for (int u = 0; u < ASM_PAIR_U; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
     }
     // lane (j, g) holds rows g + 4 r of column j: block one = r 0,1 of columns 0..5, block two = r 2,3 of columns 8..13
     acc[0] += __shfl_down(acc[2], 8, 16);

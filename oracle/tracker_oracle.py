@@ -220,3 +220,100 @@ def track_dynamic_frame(prev_dynamic, motion_mask, flow, boundary, next_tracklet
                object_id=np.array(feats["object_id"], np.int32), flow=np.array(feats["flow"], np.float64).reshape(-1, 2),
                predicted_kp=np.array(feats["predicted_kp"], np.float64).reshape(-1, 2))
     return out, to_sample, status, tid
+
+
+def _disc(mask, x, y, r, value):
+    """cv::circle(mask, (x, y), r, value, FILLED): rows of half-width floor(sqrt(r^2 + r - dy^2)) [recalled, as flow_oracle.track_dynamic]"""
+    h, w = mask.shape
+    for dy in range(-r, r + 1):
+        yy, v = y + dy, r * r + r - dy * dy
+        if yy < 0 or yy >= h or v < 0:
+            continue
+        hw = int(np.floor(np.sqrt(v)))
+        mask[yy, max(0, x - hw):min(w - 1, x + hw) + 1] = value
+
+
+def track_dynamic_klt_frame(prev_dynamic, prev_gray, gray, motion_mask, boundary, next_tracklet_id, max_features=50, max_age=25, age_buffer=3,
+                            min_tracks=20, min_iou=0.3, min_distance=2, shrink_row=0, shrink_col=0):
+    """FeatureTracker::trackDynamicKLT (FeatureTracker.cc:500-862), the dynamic tracker used when no dense flow is provided
+    (params_.prefer_provided_optical_flow false, :125-140), for one frame:
+      :595-706  forward pyramidal LK (21x21, 3 levels, 30 iterations; klt_oracle.calc_pyr_lk - the reference runs
+                cv::cuda::SparsePyrLKOpticalFlow, whose arithmetic is not restated: the CPU lkpyramid restatement stands in) of the
+                previous frame's usable dynamic features k-1 -> k; per tracked point (status set): label under the point, detection
+                mask test (before any count), info_ bookkeeping, contained / object / same-label / shrunken-image tests, age + 1
+                (dropped beyond max_dynamic_feature_age), discs into the detection mask
+      :766-772  requiresSampling (same function as the dense-flow tracker)
+      :774-861  per object to sample: goodFeaturesToTrack(mono, 50, 0.01, min_distance, (mask == object) & detection mask),
+                ANMS RangeTree to max_features - num_track (tolerance 0.01), new features of age 0 inside the shrunken image
+    prev_dynamic: None or dict(tracklet_id, kp, age, object_id) of frame k-1; gray images uint8.
+    Undefined in the reference and fixed here (and in the product): objects are sampled in ascending id (the reference fills a
+    tbb::concurrent_unordered_map), corners keep the detector's order through the response sort (all responses are equal), a tracked
+    point outside the image is dropped (the reference indexes the mask out of bounds).  The features of frame k carry no flow in this
+    mode (the reference writes kp_k - kp_{k-1} into the PREVIOUS frame's feature).  PARITY UNPINNED against the binary."""
+    from . import gftt_oracle as GO
+    from . import klt_oracle as KO
+    h, w = motion_mask.shape
+    status, tracked = {}, {}
+    det = np.asarray(boundary["boundary_mask"], np.uint8).copy()
+    feats = dict(tracklet_id=[], kp=[], age=[], object_id=[])
+    tid = int(next_tracklet_id)
+    if prev_dynamic is not None and len(prev_dynamic["tracklet_id"]):
+        prev_pts = np.asarray(prev_dynamic["kp"], np.float64).reshape(-1, 2).astype(np.float32)     # toOpenCV: cv::Point2f
+        cur, st = KO.calc_pyr_lk(prev_gray, gray, prev_pts, None, 3, 30, 0.03)
+        per_obj = {}
+        for i in range(len(prev_pts)):
+            if not st[i]:
+                continue
+            kx, ky = float(cur[i][0]), float(cur[i][1])
+            x, y = int(kx), int(ky)
+            if not (0 <= x < w and 0 <= y < h):
+                continue
+            lab = int(motion_mask[y, x])
+            if det[y, x] == 0:
+                continue
+            prev_lab = int(prev_dynamic["object_id"][i])
+            s = status.setdefault(lab, _status())
+            s["num_previous_track"] += 1
+            if lab == 0:
+                s["num_tracked_with_background_label"] += 1
+            if lab != prev_lab:
+                s["num_tracked_with_different_label"] += 1
+            contained = kx >= 0.0 and kx < w and ky >= 0.0 and ky < h
+            if not (contained and lab != 0 and lab == prev_lab):
+                continue
+            if not bool(within_shrunken(x, y, w, h, shrink_row, shrink_col)):
+                s["num_outside_shrunken_image"] += 1
+                continue
+            age = int(prev_dynamic["age"][i]) + 1
+            if age > max_age:
+                continue
+            per_obj.setdefault(lab, []).append((int(prev_dynamic["tracklet_id"][i]), (kx, ky), age))
+            s["num_track"] += 1
+            _disc(det, x, y, min_distance, 0)
+        for lab in sorted(per_obj):
+            for t_, kp_, a_ in per_obj[lab]:
+                feats["tracklet_id"].append(t_); feats["kp"].append(kp_); feats["age"].append(a_); feats["object_id"].append(lab)
+            tracked[lab] = dict(age=np.array([a for _, _, a in per_obj[lab]]), kp=np.array([k for _, k, _ in per_obj[lab]], np.float64))
+    to_sample, why = requires_sampling(boundary["objects"], boundary["inner_boxes"], tracked, set(status), max_age, age_buffer, min_tracks, min_iou)
+    for o in to_sample:
+        s = status.setdefault(o, _status())
+        s["object_resampled"] = True
+        if why[o]["new"]:
+            s["object_new"] = True
+    for o in to_sample:
+        combined = ((motion_mask == o) & (det != 0)).astype(np.uint8) * 255
+        corners, _ = GO.good_features_to_track(gray, combined, max_features, 0.01, float(min_distance))
+        need = max(max_features - status[o]["num_track"], 0)
+        if len(corners) == 0:
+            continue                                  # suppressNonMax returns before anything is counted; num_sampled = 0 then
+        keep = anms_range_tree(corners, need, 0.01, w, h)
+        status[o]["num_sampled"] = len(keep)
+        for i in keep:
+            kx, ky = float(corners[i][0]), float(corners[i][1])
+            if not bool(within_shrunken(int(kx), int(ky), w, h, shrink_row, shrink_col)):
+                continue
+            feats["tracklet_id"].append(tid); tid += 1
+            feats["kp"].append((kx, ky)); feats["age"].append(0); feats["object_id"].append(int(o))
+    out = dict(tracklet_id=np.array(feats["tracklet_id"], np.int64), kp=np.array(feats["kp"], np.float64).reshape(-1, 2), age=np.array(feats["age"], np.int64),
+               object_id=np.array(feats["object_id"], np.int32))
+    return out, to_sample, status, tid

@@ -61,3 +61,41 @@ def test_sample_dynamic_candidate_rule():
     assert np.allclose(r["predicted_kp"], r["kp"] + 1.0)
     inside_blank = (r["kp"][:, 1] < 15) & (r["kp"][:, 0] >= 40)
     assert not inside_blank.any()
+
+
+def test_track_dynamic_klt_frame_keeps_features_on_their_objects():
+    """the restated trackDynamicKLT on a small rendered stream: tracked features stay on their object and age by one, features
+    beyond max_dynamic_feature_age are dropped, new objects / thinned objects are re-sampled up to max_features, ids are unique"""
+    from dynosam_amd import synth_images as SI
+    from dynosam_amd.feature_tracker import boarder_thickness
+    from oracle import klt_oracle as KO
+    from oracle import mask_oracle as MO
+    from oracle import tracker_oracle as TO
+    W, H = 320, 240
+    rgb, mask = SI.make_sequence(W, H, objects=2, frames=6, seed=29)
+    prev, tid, pg = None, 7, None
+    seen = set()
+    for k in range(5):
+        g = KO.gray_u8(rgb[k])
+        bm = MO.boundary_mask(mask[k], boarder_thickness(W, H), True)
+        dyn, ts, st, tid2 = TO.track_dynamic_klt_frame(prev, pg, g, mask[k], dict(boundary_mask=bm["boundary_mask"], objects=bm["objects"], inner_boxes=bm["inner_boxes"]),
+                                                       tid, max_age=3, age_buffer=1)
+        ids, kp, age, obj = dyn["tracklet_id"], dyn["kp"], dyn["age"], dyn["object_id"]
+        assert len(np.unique(ids)) == len(ids)
+        assert (mask[k][kp[:, 1].astype(int), kp[:, 0].astype(int)] == obj).all()
+        assert age.max() <= 3
+        new = ids[age == 0]
+        assert np.array_equal(new, np.arange(tid, tid2)) and not (set(new.tolist()) & seen)      # fresh ids, in order
+        if prev is not None:
+            a = {int(t): i for i, t in enumerate(prev["tracklet_id"])}
+            for i in np.nonzero(age > 0)[0]:
+                j = a[int(ids[i])]
+                assert age[i] == prev["age"][j] + 1 and obj[i] == prev["object_id"][j]
+                assert np.abs(kp[i] - prev["kp"][j]).max() < 12.0                                  # the scene moves a few pixels per frame
+            assert (age > 0).sum() >= (60 if k <= 3 else 5)          # frame 4: the first generation turns 4 and is dropped
+        for o in ts:
+            assert st[o]["object_resampled"] and (obj == o).sum() <= 50 + 0
+        if k == 0:
+            assert ts == sorted(bm["objects"]) and all(st[o]["object_new"] for o in ts)
+        seen |= set(ids.tolist())
+        prev, pg, tid = dict(tracklet_id=ids, kp=kp, age=age, object_id=obj), g, tid2

@@ -94,7 +94,7 @@ def test_track_dynamic_klt_frame_keeps_features_on_their_objects():
                 assert np.abs(kp[i] - prev["kp"][j]).max() < 12.0                                  # the scene moves a few pixels per frame
             assert (age > 0).sum() >= (60 if k <= 3 else 5)          # frame 4: the first generation turns 4 and is dropped
         for o in ts:
-            assert st[o]["object_resampled"] and (obj == o).sum() <= 50 + 0
+            assert st[o]["object_resampled"] and (obj == o).sum() <= 50 + 5          # ANMS stops within its tolerance band or when the search width repeats
         if k == 0:
             assert ts == sorted(bm["objects"]) and all(st[o]["object_new"] for o in ts)
         seen |= set(ids.tolist())

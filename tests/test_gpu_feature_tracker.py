@@ -165,3 +165,24 @@ def test_klt_dynamic_tracker_matches_restated_bookkeeping_and_the_native_tracker
         prev_gray = gray
     assert sampled >= 3 and tracked_n > 40 and expired > 0
     a.close(); b.close()
+
+
+def test_klt_mode_edge_cases():
+    """KLT mode needs frame k in every call; a stream without objects yields no dynamic features; objects appearing later are sampled then"""
+    from dynosam_amd._lib import DynoError
+    from dynosam_amd.feature_tracker import NativeFeatureTracker
+    W, H = 320, 240
+    rgb, mask = SI.make_sequence(W, H, objects=1, frames=4, seed=31)
+    p = TrackerParams(prefer_provided_optical_flow=False, max_features_per_frame=120, min_features_per_frame=60)
+    t = NativeFeatureTracker(W, H, p)
+    empty = np.zeros_like(mask[0])
+    f0 = t.track(0, 0.0, rgb[0], empty)
+    assert len(f0.dynamic) == 0 and f0.objects == [] and f0.retracked_objects == [] and len(f0.static) > 40
+    f1 = t.track(1, 0.1, rgb[1], mask[1])                 # the object shows up: new -> sampled
+    assert f1.retracked_objects == f1.objects == [1] and len(f1.dynamic) > 20 and (f1.dynamic.age == 0).all()
+    assert f1.info["dynamic_track"][1]["object_new"] and f1.info["dynamic_track"][1]["num_sampled"] >= len(f1.dynamic)
+    f2 = t.track(2, 0.2, rgb[2], mask[2])
+    assert (f2.dynamic.age > 0).sum() > 15 and set(f2.dynamic.tracklet_id[f2.dynamic.age > 0]) <= set(f1.dynamic.tracklet_id)
+    with pytest.raises((DynoError, AttributeError, ValueError, TypeError)):
+        t.track(3, 0.3, None, mask[3])
+    t.close()

@@ -173,3 +173,33 @@ def test_backend_loop_in_the_library(kind):
             hp.set_values(list(kp), sp); hn.set_values(kn, sn)
     assert n_opt >= 3
     wp.ctx.close(); wn.ctx.close(); hn.close()
+
+
+@pytest.mark.parametrize("kind", ["hybrid", "wcme"])
+def test_stereo_static_updater_matches_the_python_builder(kind):
+    """static_formulation_type = 2 (the shipped flag): GenericStereoFactor on the fake stereo rig - DLT triangulation (one-sided
+    Jacobi SVD in the library, numpy's LAPACK SVD in Python) over every observation so far, reprojection and disparity gates,
+    outlier marking; with and without carried keypoints, noisy measurements, a wild observation and a far point"""
+    cal = F.StereoCalibration(fx=700.0, fy=700.0, u0=320.0, v0=240.0, baseline=0.12, pixel_sigma=1.0)
+    rng = np.random.default_rng(8)
+    pk, _ = make_stream(n_frames=10, seed=6)
+    for i, p in enumerate(pk):
+        p.static = p.static.copy()
+        p.static[:, 1:] += rng.normal(0, 0.004, p.static[:, 1:].shape)
+        extra = [[900, 0.0, 0.0, 400.0]]                                  # far point: disparity below the gate, never inserted
+        if i in (2, 3, 4):
+            extra.append([901, 0.5 + (3.0 if i == 3 else 0.0), 0.2, 7.0])    # a wild observation in the middle of a track: rejected as outlier
+        p.static = np.concatenate([p.static, np.array(extra)])
+        if i % 2 == 0:                                                    # every other frame carries keypoints (slightly off the projection)
+            z = p.static[:, 1:]
+            p.static_kp = np.stack([cal.fx * z[:, 0] / z[:, 2] + cal.u0, cal.fy * z[:, 1] / z[:, 2] + cal.v0], -1) + rng.normal(0, 0.2, (len(z), 2))
+    hp, hn = PY[kind](static_formulation="stereo", stereo=cal), F.NativeFormulation(kind, static_formulation="stereo", stereo=cal)
+    for p in pk:
+        span = hp.update(p)
+        vp, bp = hp.new_values_and_factors(span)
+        vn, bn = hn.update(p)
+        compare_spin(vp, bp, vn, bn, tol=1e-9)                            # triangulated points: two different SVD algorithms
+    assert hn.counts() == (len(hp.theta), len(hp.factors))
+    assert any(f[0] == 6 for f in hp.factors) and not any(f[0] == 2 and int(f[1][1]) >> 56 == ord("l") for f in hp.factors)
+    assert len(hp.static_outliers) >= 1 and int(F.S.StaticLandmarkSymbol(900)) not in hp.theta
+    hn.close()

@@ -300,3 +300,51 @@ def test_c_example_runs_the_backend(tmp_path):
     for ln in lines:
         e0, e1 = [float(x) for x in ln.split("error ")[1].split(",")[0].split(" -> ")]
         assert e1 < e0
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_streams(seed):
+    """randomised streams (objects appearing, vanishing for a random number of frames and coming back, tracklets of random length, frames
+    without motion estimates, optional smoothing / VO, random gates): the C++ builder and the Python builder produce the same graph -
+    or fail the same bookkeeping check of the reference in the same frame"""
+    from dynosam_amd._lib import DynoError
+    rng = np.random.default_rng(1000 + seed)
+    kind = ["hybrid", "wcme", "wcpe"][seed % 3]
+    n_frames, NO = int(rng.integers(10, 22)), int(rng.integers(1, 4))
+    X = [(np.eye(3), np.zeros(3))]
+    for _ in range(n_frames - 1):
+        X.append(compose(X[-1], se3_exp(np.array([0.003, 0.002, 0.0, 0.014, 0.038, 0.0]) + rng.normal(0, 0.002, 6))))
+    Hs = [se3_exp(rng.normal(0, 0.03, 6)) for _ in range(NO)]
+    L = [[(np.eye(3), rng.uniform([-2, -1, 6], [2, 1, 12]))] for _ in range(NO)]
+    for j in range(NO):
+        for _ in range(n_frames - 1):
+            L[j].append(compose(Hs[j], L[j][-1]))
+    NS, ND = int(rng.integers(20, 80)), int(rng.integers(6, 25))
+    stat = rng.uniform([-4, -3, 5], [4, 3, 20], (NS, 3))
+    s_win = [(int(a), int(a + d)) for a, d in zip(rng.integers(0, n_frames - 1, NS), rng.integers(0, 8, NS))]
+    body = rng.normal(0, 0.4, (NO, ND, 3))
+    d_win = [[(int(a), int(a + d)) for a, d in zip(rng.integers(0, n_frames - 2, ND), rng.integers(1, 10, ND))] for _ in range(NO)]
+    hidden = [set(int(f) for f in rng.choice(np.arange(2, n_frames), size=int(rng.integers(0, 5)), replace=False)) for _ in range(NO)]   # frames the object is not seen
+    pk = []
+    for k in range(n_frames):
+        st = [(100 + i, *act(inverse(X[k]), stat[i])) for i, (a, b) in enumerate(s_win) if a <= k <= b]
+        dy = [(5000 + 100 * j + i, j + 1, *act(inverse(X[k]), act(L[j][k], body[j][i]))) for j in range(NO) if k not in hidden[j]
+              for i, (a, b) in enumerate(d_win[j]) if a <= k <= b]
+        seen = {int(r[1]) for r in dy}
+        mot = {j + 1: to12(compose(Hs[j], se3_exp(rng.normal(0, 0.003, 6)))) for j in range(NO) if (j + 1) in seen and k > 0 and rng.uniform() > 0.1}
+        T = to12(compose(inverse(X[k - 1]), X[k])) if k else None
+        pk.append(F.FramePacket(k, to12(X[k]), T, np.array(st).reshape(-1, 4), np.array(dy).reshape(-1, 5), mot))
+    kw = dict(use_smoothing_factor=bool(rng.integers(0, 2)), use_vo=bool(rng.integers(0, 2)),
+              params=F.BackendParams(min_static_observations=int(rng.integers(1, 4)), min_dynamic_observations=int(rng.integers(3, 5)), use_robust_kernels=bool(rng.integers(0, 2))))
+    hp, hn = PY[kind](**kw), F.NativeFormulation(kind, **kw)
+    for p in pk:
+        try:
+            span = hp.update(p)
+        except AssertionError:                                    # the reference's CHECK (HybridEstimator.cc:960-975)
+            with pytest.raises(DynoError):
+                hn.update(p)
+            break
+        vp, bp = hp.new_values_and_factors(span)
+        vn, bn = hn.update(p)
+        compare_spin(vp, bp, vn, bn)
+    hn.close()

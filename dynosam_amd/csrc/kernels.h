@@ -1223,12 +1223,22 @@ __global__ __launch_bounds__(256) void k_rhs(RhsView R, const double* const* __r
                                              const double* __restrict__ uq, double* __restrict__ gc) {
   rhs_body(R, Jpp, Z, uq, gc, (int)blockIdx.x);
 }
-// k_assemble_chunks and k_rhs in ONE launch (both only read Z / u / the records): workgroups [0, n_asm) assemble, the rest form the
-// reduced gradient - the two kernels are latency bound and used to run one after the other on the solve's critical path
-__global__ __launch_bounds__(256) void k_assemble_rhs(AssembleView A, RhsView R, const double* const* __restrict__ Jpp, const double* __restrict__ Z,
+// k_assemble_chunks and k_rhs in ONE launch (both only read Z / u / the records): the first gridDim - n_asm workgroups form the reduced
+// gradient, the other n_asm assemble - the two kernels are latency bound and used to run one after the other on the solve's critical path
+// 8 waves per SIMD (64 VGPRs, 5 spilled): the launch is a latency-bound gather, what it needs is waves in flight - 267 -> 239 us for the
+// assembly phase and 1.62 -> 1.58 ms per LM iteration against the 5 waves the unconstrained 70 VGPRs gave (same idea measured on k_edge_z and
+// k_trial_errors_fused: their spills cost more than the extra waves bring)
+#ifndef ASM_WAVES
+#define ASM_WAVES 8
+#endif
+__global__ __launch_bounds__(256, ASM_WAVES) void k_assemble_rhs(AssembleView A, RhsView R, const double* const* __restrict__ Jpp, const double* __restrict__ Z,
                                                       const double* __restrict__ uq, double* __restrict__ partial, double* __restrict__ gc, int n_asm) {
-  if ((int)blockIdx.x < n_asm) asm_chunks_body(A, Jpp, Z, partial, (int)blockIdx.x, n_asm);
-  else rhs_body(R, Jpp, Z, uq, gc, (int)blockIdx.x - n_asm);
+  // the gradient workgroups go first: a camera pose walks ~500 edges in one wave, the longest task of the launch (measured: 272 -> 270 us
+  // for the assembly phase against dispatching them behind the ~8 k assembly workgroups).  n_rhs is a multiple of 8: the assembly keeps
+  // its XCD mapping.
+  const int n_rhs = (int)gridDim.x - n_asm;
+  if ((int)blockIdx.x < n_rhs) rhs_body(R, Jpp, Z, uq, gc, (int)blockIdx.x);
+  else asm_chunks_body(A, Jpp, Z, partial, (int)blockIdx.x - n_rhs, n_asm);
 }
 
 // scatter g' (and, multi-GPU, the damping) into the rhs tile row / diagonal

@@ -5,13 +5,13 @@
 // system, after the points were marginalised by k_point/k_edge_z/k_assemble.
 //
 //   k_chol_level   one workgroup (4 wavefronts) per task of one forward launch:
-//                    update   A(I,I') -= P Q^T,  P = A(I,K) Linv_K^T, Q = A(I',K) Linv_K^T
-//                             — three 32x32x32 fp64 contractions on v_mfma_f64_16x16x4_f64,
-//                               operands staged in LDS (leading dimension 33: conflict-free C-fragment stores)
-//                    panel    L(I,K) = A(I,K) Linv_K^T                       (needed by the backward pass)
-//                    diagonal targets also carry the rhs segment  r_I -= A(I,K) w_K
-//                    finalize the workgroup applying the LAST update to a diagonal tile factors it in
-//                             place and forms its inverse (look-ahead), see tall_potrf below
+//                    update   A(I,I') -= P' A(I',K)^T,  P' = A(I,K) T_K^-1   (T_K: the Schur complement of column K when it
+//                             is eliminated) - two 32x32x32 fp64 contractions on v_mfma_f64_16x16x4_f64, operands staged
+//                             in LDS (leading dimension 33: conflict-free C-fragment stores)
+//                    diagonal targets also carry the rhs segment  r_I -= A(I,K) w_K = P' r_K
+//                    finalize the workgroup applying the LAST update to a diagonal tile inverts it straight from its
+//                             accumulators (look-ahead), see ct_spd_inverse below: only T_K^-1 is ever used
+//   k_panel_m      M(I,K) = A(I,K) T_K^-1 (backward pass operands) and w_K = T_K^-1 r_K, one launch after the factorisation
 //   k_back_group   backward substitution, BWD_GROUP levels per launch
 //
 // All arithmetic fp64.  Every reduction has a fixed order: results are run-to-run deterministic.
@@ -157,140 +157,147 @@ __device__ __forceinline__ ct_d4 ct_load_frag(const double* __restrict__ T, int 
 }
 
 // ------------------------------------------------------------------------------------------
-// Cholesky of a 32x32 tile AND the inverse of its factor, one pass, by 4 wavefronts.
+// Inverse of a 32x32 SPD tile T by 4 wavefronts, in the accumulator layout of the update that produced it.
 //
-// The tile is extended to a 64x32 "tall" tile [T; I].  A right-looking blocked factorisation
-// applied to all 64 rows leaves  L  in the top half and  I L^-T = Linv^T  in the bottom half, so
-// the inverse costs no extra dependent steps.  Wave w owns rows 16w..16w+15 (two 16x16
-// accumulator fragments c0 | c1 that never leave registers).  Per block of NB columns:
-//   1. the lanes holding those columns publish them to an LDS panel (double buffered, ONE barrier)
-//   2. EVERY lane factors the NB x NB diagonal block and inverts the factor in registers
-//      (redundant; no cross-lane traffic on the dependent rsqrt chain)
-//   3. each lane forms its MFMA operand X[i][k] = sum_m panel[i][m] W[k][m] directly, the trailing
-//      update c -= X X^T is NB/4 MFMAs per fragment, and the same X values ARE the output columns.
+// The blocked algorithm only ever uses T_K^-1 (updates: P' = A(I,K) T_K^-1, panels: M = A T^-1, rhs: w = T^-1 r), so no
+// triangular factor is formed.  The bordered matrix [[T, I], [I, 0]] is eliminated by a right-looking block LDL^T with 4x4
+// pivot blocks D_b: after the 32 columns of T are gone, the Schur complement in the lower right corner is -T^-1.
+//   top  (bi, bj)  block of T itself            (the update's accumulator: no re-layout)
+//   g    (bi, bj)  block of the lower-left I    (becomes the unit upper triangular L~^-T; block (1, 0) stays zero)
+//   ti   (bi, bj)  block of the lower-right 0   (ends as -T^-1; only the lower blocks (0,0) (1,0) (1,1) are formed)
+// Wave w = 2 bi + bj owns the three 16x16 fragments of "its" block.  Per pivot block (8 of them, ONE barrier each):
+//   1. the waves holding columns cb..cb+3 publish them (rows of T and of g) to an LDS panel, double buffered
+//   2. EVERY lane factors the 4x4 pivot block D_b = L D L^T in registers (redundant: no cross-lane traffic on the dependent
+//      chain; reciprocals by v_rcp_f64 + ONE third-order step, the raw seed is good to 2^-24: scripts/ubench/dp_lat.hip) and
+//      solves for column lr of D_b^-1 - exactly the column its MFMA operand needs, so there is no select and no row solve
+//   3. the A operand of a row is  (panel row) . (that column),  the B operand is the RAW panel row of the column index
+//      (the bordered matrix is symmetric), and the trailing update is one MFMA per fragment that still has live columns.
+// A v_*_f64 instruction issues every ~5.2 cycles whether it depends on the previous one or not (dp_lat.hip), so the count of
+// fp64 instructions per pivot block (~60 here, ~150 in the Cholesky + triangular inverse this replaces) is what sets the time.
 // ------------------------------------------------------------------------------------------
-template <int NB>
-struct CtBlk {            // per-lane (redundant) factorisation of one NB x NB diagonal block, LDL^T form
-  double T[NB][NB];       // T[i][k] = C[i][k] / d_k  (i > k), C = running Schur complement
-  double rs[NB];          // 1 / sqrt(d_k)
-};
-// X = p L^-T for one row of the panel (p = NB values at pb[row*NB ..]); returns the NB/4 MFMA operands
-// X[lr + 4 kk] of this lane.
-template <int NB>
-__device__ __forceinline__ void ct_row_solve(const CtBlk<NB>& B, const double* __restrict__ rsel, const double* __restrict__ prow, int lr,
-                                             double* __restrict__ out) {
-  double x[NB];
-#pragma unroll
-  for (int k = 0; k < NB; ++k) {
-    double v = prow[k];
-#pragma unroll
-    for (int m = 0; m < k; ++m) v = fma(-x[m], B.T[k][m], v);
-    x[k] = v;
-  }
-#pragma unroll
-  for (int kk = 0; kk < NB / 4; ++kk) {
-    double v = x[4 * kk];
-#pragma unroll
-    for (int q = 1; q < 4; ++q) v = (lr == q) ? x[4 * kk + q] : v;
-    out[kk] = v * rsel[kk];
-  }
+// A pivot is accepted when it exceeds its own rounding error: it is what remains of the row's un-reduced Hessian diagonal
+// h (hd[], kernels.h: k_assemble_final_tiles) after every Schur complement was subtracted, so it carries an absolute error
+// of a few ulp of h.  gtsam (Eigen LLT inside choleskyPartial) fails on d <= 0, which for a rank-deficient block - an object
+// motion whose points were all seen once - is a coin toss on the sign of that error; d <= 64 ulp(h) makes the
+// IndeterminantLinearSystemException deterministic (h = 0 on padding rows, whose unit diagonal passes).
+#define CT_PIVOT_TOL 0x1p-46
+__device__ __forceinline__ double ct_rcp3(double x) {
+  const double r = __builtin_amdgcn_rcp(x);
+  const double e = fma(-x, r, 1.0);
+  return fma(r, fma(e, e, e), r);          // r (1 + e + e^2): relative error e^3
 }
 
-template <int NB>
-__device__ __forceinline__ void ct_tall_potrf(ct_d4 c0, ct_d4 c1, double* __restrict__ pan /*2*64*NB*/, double* __restrict__ Lout,
-                                              double* __restrict__ LIout, int tid, int col0, int* __restrict__ fail) {
-  const int w = tid >> 6, lane = tid & 63, lr = lane >> 4, lc = lane & 15;
-  const int irow = 16 * w + lc;   // operand row of this lane in the tall tile
-  bool ok = true;
+#ifndef CT_INV_UNROLL
+#define CT_INV_UNROLL 8
+#endif
+#define CT_PRAGMA(x) _Pragma(#x)
+#define CT_UNROLL(n) CT_PRAGMA(unroll n)
+__device__ __forceinline__ ct_d4 ct_spd_inverse(ct_d4 top, double* __restrict__ pan /* 2 x 64 x 4 */, int tid, int col0, const double* __restrict__ hd /* 32 pivot scales */,
+                                                int* __restrict__ fail, long long* __restrict__ dbg = nullptr) {
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lr = lane >> 4, lc = lane & 15, bi = w >> 1, bj = w & 1;
+  ct_d4 g, ti = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int r = 0; r < 4; ++r) g[r] = (bi == bj && lr + 4 * r == lc) ? 1.0 : 0.0;
+  if (bi < bj) top = ti;                   // the upper block is never read; it only has to stay finite
+  const double e0 = lr == 0 ? 1.0 : 0.0, e1 = lr == 1 ? 1.0 : 0.0, e2 = lr == 2 ? 1.0 : 0.0, e3 = lr == 3 ? 1.0 : 0.0;
+  // pivot thresholds: lane l holds the one of column l & 31, broadcast with v_readlane when its pivot comes up (a load per pivot
+  // block would sit on the dependent chain)
+  const double hv = CT_PIVOT_TOL * hd[lane & 31];
+  auto thr = [&](int c) {
+    const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)__double_as_longlong(hv), c);
+    const unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)__double_as_longlong(hv) >> 32), c);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+  };
   int bad = 0x7fffffff;
+  // the T^-1 accumulation of a step is off the dependent chain (nothing reads ti before the end): its MFMA is issued one step
+  // late, into the LDS wait of the next step, instead of in front of the publication the next step waits for
+  double ab_late = 0.0, bb_late = 0.0;
+  bool ti_late = false;
+  CT_UNROLL(CT_INV_UNROLL)
+  for (int kb = 0; kb < CT_TS / 4; ++kb) {
+    const int cb = 4 * kb, pbj = cb >> 4, cin = cb & 15;
+    if (dbg && kb) dbg[6 + kb] = (long long)__builtin_readcyclecounter();   // (debug tap: start of pivot blocks 1..7)
+    // which fragments still change at this pivot block (wave-uniform)
+    const bool n_top = bi >= bj && cb + 4 < 16 * (bj + 1);
+    const bool n_g = bi <= bj && cb + 4 < 16 * (bj + 1) && 16 * bi <= cb + 3;
+    const bool n_ti = bi >= bj && 16 * bi <= cb + 3;
+    double* pb = pan + (kb & 1) * 256;
+    if (bj == pbj && lc >= cin && lc < cin + 4) {
+      if (bi >= bj) {
 #pragma unroll
-  for (int kb = 0; kb < CT_TS / NB; ++kb) {
-    const int cbase = NB * kb, bj = cbase >> 4, cin = cbase & 15;
-    double* pb = pan + (kb & 1) * 64 * NB;
-    if (lc >= cin && lc < cin + NB) {
-      const ct_d4 s = bj ? c1 : c0;
+        for (int r = 0; r < 4; ++r) pb[(16 * bi + lr + 4 * r) * 4 + (lc - cin)] = top[r];
+      }
+      if (bi <= bj) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) pb[(16 * w + lr + 4 * r) * NB + (lc - cin)] = s[r];
-    }
-    __syncthreads();
-    // LDL^T form: T = C / d, outputs scaled by rs = 1/sqrt(d) afterwards.  The wave is issue bound here
-    // (one wave per SIMD, ~5 cycles per fp64 op), so the op count per pivot is what matters.
-    CtBlk<NB> B;
-    {
-      double C[NB][NB];
-#pragma unroll
-      for (int i = 0; i < NB; ++i)
-#pragma unroll
-        for (int j = 0; j <= i; ++j) C[i][j] = pb[(cbase + i) * NB + j];
-#pragma unroll
-      for (int k = 0; k < NB; ++k) {
-        double d = C[k][k];
-        const bool pos = d > 0.0;
-        if (!pos && ok) { ok = false; bad = col0 + cbase + k; }
-        d = pos ? d : 1.0;
-        B.rs[k] = ct_rsqrt(d);
-        const double inv = B.rs[k] * B.rs[k];
-#pragma unroll
-        for (int i = k + 1; i < NB; ++i) B.T[i][k] = C[i][k] * inv;
-#pragma unroll
-        for (int i = k + 1; i < NB; ++i)
-#pragma unroll
-          for (int j = k + 1; j <= i; ++j) C[i][j] = fma(-B.T[i][k], C[j][k], C[i][j]);
+        for (int r = 0; r < 4; ++r) pb[(32 + 16 * bi + lr + 4 * r) * 4 + (lc - cin)] = g[r];
       }
     }
-    const bool need0 = cbase + NB < 16;    // fragment c0 (columns 0..15) still has unfinished columns
-    double xa[NB / 4], xb0[NB / 4], xb1[NB / 4], rsel[NB / 4];
-#pragma unroll
-    for (int kk = 0; kk < NB / 4; ++kk) {
-      double v = B.rs[4 * kk];
-#pragma unroll
-      for (int q = 1; q < 4; ++q) v = (lr == q) ? B.rs[4 * kk + q] : v;
-      rsel[kk] = v;
-    }
-    ct_row_solve<NB>(B, rsel, pb + irow * NB, lr, xa);
-    if (w == 0) {
-#pragma unroll
-      for (int kk = 0; kk < NB / 4; ++kk) xb0[kk] = xa[kk];
-    } else if (need0) {
-      ct_row_solve<NB>(B, rsel, pb + lc * NB, lr, xb0);
-    }
-    if (w == 1) {
-#pragma unroll
-      for (int kk = 0; kk < NB / 4; ++kk) xb1[kk] = xa[kk];
-    } else {
-      ct_row_solve<NB>(B, rsel, pb + (16 + lc) * NB, lr, xb1);
-    }
-#pragma unroll
-    for (int kk = 0; kk < NB / 4; ++kk) {
-      if (need0) c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa[kk], xb0[kk], c0, 0, 0, 0);
-      if (cbase + NB < 32) c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa[kk], xb1[kk], c1, 0, 0, 0);
-      const int kcol = cbase + 4 * kk + lr;
-      if (w < 2) Lout[irow + CT_LD * kcol] = (irow >= kcol) ? xa[kk] : 0.0;
-      else LIout[kcol + CT_LD * (irow - 32)] = xa[kk];     // Linv[kcol][i'] = (Linv^T)[i'][kcol]
-    }
+    __syncthreads();
+    // every LDS read of the step is issued here, unconditionally, so that the panel rows travel while the pivot block is factored
+    const double2* pp = reinterpret_cast<const double2*>(pb + cb * 4);
+    const double c00 = pp[0].x;
+    const double2 q1 = pp[2], q2a = pp[4], q2b = pp[5], q3a = pp[6], q3b = pp[7];
+    const double2* prt = reinterpret_cast<const double2*>(pb + (16 * bi + lc) * 4);
+    const double2* prb = reinterpret_cast<const double2*>(pb + (32 + 16 * bi + lc) * 4);
+    const double2 ut = prt[0], vt = prt[1], ub = prb[0], vb = prb[1];
+    const double bt = pb[(16 * bj + lc) * 4 + lr], bb = pb[(32 + 16 * bj + lc) * 4 + lr];
+    __builtin_amdgcn_sched_barrier(0);     // (keep the reads up here: the scheduler would sink them below the factorisation)
+    if (ti_late) ti = __builtin_amdgcn_mfma_f64_16x16x4f64(ab_late, bb_late, ti, 0, 0, 0);      // accumulates +T^-1
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- the 4x4 pivot block (lower triangle of rows cb..cb+3), L D L^T ----
+    double d0 = c00;
+    { const bool pos = d0 > thr(cb); bad = pos ? bad : min(bad, col0 + cb); d0 = pos ? d0 : 1.0; }
+    const double r0 = ct_rcp3(d0);
+    const double l10 = q1.x * r0, l20 = q2a.x * r0, l30 = q3a.x * r0;
+    double d1 = fma(-l10, q1.x, q1.y);
+    const double c21 = fma(-l20, q1.x, q2a.y), c31 = fma(-l30, q1.x, q3a.y);
+    { const bool pos = d1 > thr(cb + 1); bad = pos ? bad : min(bad, col0 + cb + 1); d1 = pos ? d1 : 1.0; }
+    const double r1 = ct_rcp3(d1);
+    const double l21 = c21 * r1, l31 = c31 * r1;
+    double d2 = fma(-l21, c21, fma(-l20, q2a.x, q2b.x));
+    const double c32 = fma(-l31, c21, fma(-l30, q2a.x, q3b.x));
+    { const bool pos = d2 > thr(cb + 2); bad = pos ? bad : min(bad, col0 + cb + 2); d2 = pos ? d2 : 1.0; }
+    const double r2 = ct_rcp3(d2);
+    const double l32 = c32 * r2;
+    double d3 = fma(-l32, c32, fma(-l31, c31, fma(-l30, q3a.x, q3b.y)));
+    { const bool pos = d3 > thr(cb + 3); bad = pos ? bad : min(bad, col0 + cb + 3); d3 = pos ? d3 : 1.0; }
+    const double r3 = ct_rcp3(d3);
+    // ---- column lr of D_b^-1:  L y = e_lr,  z = D^-1 y,  L^T x = z ----
+    const double y1 = fma(-l10, e0, e1);
+    const double y2 = fma(-l21, y1, fma(-l20, e0, e2));
+    const double y3 = fma(-l32, y2, fma(-l31, y1, fma(-l30, e0, e3)));
+    const double x3 = y3 * r3;
+    const double x2 = fma(-l32, x3, y2 * r2);
+    const double x1 = fma(-l31, x3, fma(-l21, x2, y1 * r1));
+    const double x0 = fma(-l30, x3, fma(-l20, x2, fma(-l10, x1, e0 * r0)));
+    // ---- operands and trailing updates ----
+    // (both products unconditionally: a use under a wave-uniform branch makes the compiler sink the panel reads into it)
+    const double at = fma(vt.y, x3, fma(vt.x, x2, fma(ut.y, x1, ut.x * x0)));
+    const double ab = fma(vb.y, x3, fma(vb.x, x2, fma(ub.y, x1, ub.x * x0)));
+    if (n_top) top = __builtin_amdgcn_mfma_f64_16x16x4f64(-at, bt, top, 0, 0, 0);
+    if (n_g) g = __builtin_amdgcn_mfma_f64_16x16x4f64(-ab, bt, g, 0, 0, 0);
+    ab_late = ab; bb_late = bb; ti_late = n_ti;
   }
-  if (!ok && tid == 0) atomicMin(fail, bad);
-  __syncthreads();
+  if (ti_late) ti = __builtin_amdgcn_mfma_f64_16x16x4f64(ab_late, bb_late, ti, 0, 0, 0);
+  if (bad != 0x7fffffff && tid == 0) atomicMin(fail, bad);
+  return ti;
 }
 
 struct CholLevelArgs {
   const FwdTask* task;
   const FwdSrc* src;
   double* A;       // tiles of S, updated in place
-  double* L;       // tiles of the factor (same tile ids)
-  double* Linv;    // [nt] inverse diagonal factors, column-major Linv[r + 32 c]
+  double* L;       // (unused by the tile kernels: the panel products M live in this buffer)
+  double* Linv;    // (unused by the tile kernels)
   double* rhs;     // [nt*32] right-hand side, updated in place
-  double* Y;       // [nt*32] L^-1 g
-  double* Wv;      // [nt*32] Linv_K^T y_K
+  double* Y;       // [nt*32] r_K: the rhs segment of column K when it is eliminated (g_K minus every update)
+  double* Wv;      // [nt*32] w_K = T_K^-1 r_K (k_panel_m)
   int* fail;
   long long* dbg;  // optional phase timestamps of the first finalising workgroup of each launch (s_memtime ticks)
-  double* Tinv;    // [nt] T_K^-1 = Linv_K^T Linv_K, stored with Linv when the diagonal tile is factored
+  double* Tinv;    // [nt] T_K^-1, symmetric, stored when the diagonal tile is eliminated
+  const double* hdiag;   // [nt*32] un-reduced Hessian diagonal (+ damping) of every row: the scale of the pivot test
 };
 
-#ifndef CT_NB_VALUE
-#define CT_NB_VALUE 4
-#endif
-constexpr int CT_NB = CT_NB_VALUE;   // columns per panel step of the diagonal-tile factorisation
 #define CT_STAMP(k) do { if (dbg_on) a.dbg[16 * lvl + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
 
 // read a POD from the kernel-argument segment at a wave-uniform byte offset (scalar loads)
@@ -512,21 +519,33 @@ __device__ __forceinline__ void ct_run_task(const CholLevelArgs& a, const FwdTas
   double rv = 0.0;
   ct_d4 acc = ct_gload_frag_x<DF>(a.A + (int64_t)t.tgt * CT_TT, bi, bj, lane);   // the target goes straight into the accumulator layout
   if (diag && tid < CT_TS) rv = ct_ld_x<DF>(a.rhs + t.col * CT_TS + tid);
+  // rhs segment of a diagonal target: r_I -= A(I,K) w_K = P'(I,K) r_K with the product P' the update forms anyway, so the
+  // finalising workgroup of column K only has to leave its final r_K behind (a.Y), not w_K = T_K^-1 r_K
+  auto rhs_fold = [&]() {
+    if (tid < CT_TS) {
+      double ssum = 0.0;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) ssum += S.part[g][tid];
+      rv -= ssum;
+    }
+  };
   if (t.nsrc) {
     // Sources one after the other; the record and the three tiles of source q + 1 are requested before source q is computed.
     // Every load of the loop is UNCONDITIONAL (clamped index; a diagonal target fetches its operand twice, every lane fetches
-    // a w_K element): with loads under a condition the compiler waits for ALL outstanding loads before it touches any of
+    // an r_K element): with loads under a condition the compiler waits for ALL outstanding loads before it touches any of
     // them (vmcnt(0)), which turned the prefetch back into two dependent memory round trips per source.
     const int ns = t.nsrc;
     FwdSrc s{t.ai0, t.aj0, t.k0};        // the first source rides in the task record (one dependent load less on the critical path)
     FwdSrc sn = a.src[t.src0 + min(1, ns - 1)];
-    // diagonal target: P = A(I,K) Linv_K^T and A(I,I) -= P P^T (exactly symmetric); off-diagonal: P' = A(I,K) T_K^-1 and
-    // A(I,I') -= P' A(I',K)^T with the raw column operand - two contractions per source either way
-    const double* const invp = diag ? a.Linv : a.Tinv;
-    ct_t2 va = ct_gld_x<DF>(a.A + (int64_t)s.ai * CT_TT, tid), vb = ct_gld_x<DF>(a.A + (int64_t)s.aj * CT_TT, tid), vl = ct_gld_x<DF>(invp + (int64_t)s.k * CT_TT, tid);
-    double wv = ct_ld_x<DF>(a.Wv + s.k * CT_TS + (tid & 31));
+    // P' = A(I,K) T_K^-1, then A(I,I') -= P' A(I',K)^T with the raw column operand (I' = I for a diagonal target, of which
+    // only the lower triangle is ever read): two contractions per source
+    ct_t2 va = ct_gld_x<DF>(a.A + (int64_t)s.ai * CT_TT, tid), vb = ct_gld_x<DF>(a.A + (int64_t)s.aj * CT_TT, tid), vl = ct_gld_x<DF>(a.Tinv + (int64_t)s.k * CT_TT, tid);
+    double wv = ct_ld_x<DF>(a.Y + s.k * CT_TS + (tid & 31));
     for (int q = 0; q < ns; ++q) {
-      if (q) __syncthreads();            // previous source fully consumed
+      if (q) {
+        __syncthreads();                 // previous source fully consumed
+        if (diag) rhs_fold();
+      }
       ct_lst(XA, tid, va);
       if (!diag) ct_lst(XB, tid, vb);
       ct_lst(LI, tid, vl);
@@ -535,39 +554,34 @@ __device__ __forceinline__ void ct_run_task(const CholLevelArgs& a, const FwdTas
       const FwdSrc sn2 = a.src[t.src0 + min(q + 2, ns - 1)];
       va = ct_gld_x<DF>(a.A + (int64_t)sn.ai * CT_TT, tid);
       vb = ct_gld_x<DF>(a.A + (int64_t)sn.aj * CT_TT, tid);
-      vl = ct_gld_x<DF>(invp + (int64_t)sn.k * CT_TT, tid);
-      wv = ct_ld_x<DF>(a.Wv + sn.k * CT_TS + (tid & 31));
+      vl = ct_gld_x<DF>(a.Tinv + (int64_t)sn.k * CT_TT, tid);
+      wv = ct_ld_x<DF>(a.Y + sn.k * CT_TS + (tid & 31));
       s = sn; sn = sn2;
       __syncthreads();
       if (q == 0) CT_STAMP(1);
-      const ct_d4 p = ct_mma_abt<false>(XA, LI, bi, bj, lane, zero);
+      const ct_d4 p = ct_mma_abt<false>(XA, LI, bi, bj, lane, zero);   // T^-1 is stored exactly symmetric
+      __syncthreads();                   // every wave has finished LI
+      ct_store_frag(LI, bi, bj, lane, p);
+      __syncthreads();
+      acc = ct_mma_abt<true>(LI, diag ? XA : XB, bi, bj, lane, acc);
       if (diag) {
         const int i = tid & 31, kg = tid >> 5;
         double ps = 0.0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) ps = fma(XA[i + CT_LD * (4 * kg + k)], S.wk[4 * kg + k], ps);
+        for (int k = 0; k < 4; ++k) ps = fma(LI[i + CT_LD * (4 * kg + k)], S.wk[4 * kg + k], ps);
         S.part[kg][i] = ps;
       }
-      __syncthreads();                   // every wave has finished XA, LI
-      ct_store_frag(Pt, bi, bj, lane, p);
-      __syncthreads();
-      acc = ct_mma_abt<true>(Pt, diag ? Pt : XB, bi, bj, lane, acc);
-      if (diag && tid < CT_TS) {
-        double ssum = 0.0;
-#pragma unroll
-        for (int g = 0; g < 8; ++g) ssum += S.part[g][tid];
-        rv -= ssum;
-      }
     }
+    __syncthreads();                     // the operands are no longer read; the partial rhs products are complete
+    if (diag) rhs_fold();
   }
-  __syncthreads();                     // Pt/Qt no longer read as operands
   CT_STAMP(2);
 
   if (!(t.kind & FK_FINAL)) {
-    ct_store_frag(Pt, bi, bj, lane, acc);
+    ct_store_frag(XA, bi, bj, lane, acc);
     if (diag && tid < CT_TS) ct_st_x<DF>(a.rhs + t.col * CT_TS + tid, rv);
     __syncthreads();
-    ct_l2g_x<DF>(a.A + (int64_t)t.tgt * CT_TT, Pt, tid);
+    ct_l2g_x<DF>(a.A + (int64_t)t.tgt * CT_TT, XA, tid);
     if constexpr (DF) {
       CT_DF_DRAIN();
       if (tid == 0) __hip_atomic_store(sy.tile_done + t.tgt, (unsigned)sy.task_seq[ti] + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -576,63 +590,27 @@ __device__ __forceinline__ void ct_run_task(const CholLevelArgs& a, const FwdTas
     return;
   }
 
-  // ---- finalize: factor the diagonal tile, invert the factor, forward/backward-scale the rhs ----
-  ct_store_frag(Pt, bi, bj, lane, acc);
-  if (tid < CT_TS) S.rvs[tid] = rv;
-  __syncthreads();
-  ct_d4 c0, c1;
-  if (w < 2) {
-    c0 = ct_load_frag(Pt, w, 0, lane);
-    c1 = ct_load_frag(Pt, w, 1, lane);
-  } else {
-    const int lr = lane >> 4, lc = lane & 15;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int ip = 16 * (w - 2) + lr + 4 * r;   // identity row
-      c0[r] = (ip == lc) ? 1.0 : 0.0;
-      c1[r] = (ip == 16 + lc) ? 1.0 : 0.0;
-    }
-  }
+  // ---- finalize: T_K^-1 straight from the accumulators (ct_spd_inverse), r_K for the consumers ----
+  if (tid < CT_TS) ct_st_x<DF>(a.Y + t.col * CT_TS + tid, rv);
   CT_STAMP(3);
-  // outputs: L -> XA, Linv -> XB; panel buffer -> LI
-  ct_tall_potrf<CT_NB>(c0, c1, LI, XA, XB, tid, t.col * CT_TS, a.fail);
+  const ct_d4 tinv = ct_spd_inverse(acc, XA, tid, t.col * CT_TS, a.hdiag + t.col * CT_TS, a.fail, dbg_on ? a.dbg + 16 * lvl : nullptr);
   CT_STAMP(4);
-  ct_l2g(a.L + (int64_t)t.tgt * CT_TT, XA, tid);        // (read after the factorisation only)
-  ct_l2g_x<DF>(a.Linv + (int64_t)t.col * CT_TT, XB, tid);
   {
-    // T^-1 = Linv^T Linv for the off-diagonal updates and panels of the next launches (XA = L is already on its way out)
-    const ct_d4 ti2 = ct_mma_atb(XB, XB, bi, bj, lane, zero);
-    ct_gstore_frag_x<DF>(a.Tinv + (int64_t)t.col * CT_TT, bi, bj, lane, ti2);
+    // stored exactly symmetric: the lower triangle and its mirror image (the update reads T^-1 as its own transpose)
+    double* const Tg = a.Tinv + (int64_t)t.col * CT_TT;
+    const int lr = lane >> 4, lc = lane & 15;
+    if (bi >= bj) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * bi + lr + 4 * r, col = 16 * bj + lc;
+        if (row >= col) {
+          ct_st_x<DF>(Tg + row + CT_TS * col, tinv[r]);
+          if (row != col) ct_st_x<DF>(Tg + col + CT_TS * row, tinv[r]);
+        }
+      }
+    }
   }
   CT_STAMP(5);
-  {
-    // y = Linv r ; w = Linv^T y      (Linv[r][c] at XB[r + LD c], zero above the diagonal)
-    const int i = tid & 31, kg = tid >> 5;
-    double ps = 0.0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) ps = fma(XB[i + CT_LD * (4 * kg + k)], S.rvs[4 * kg + k], ps);
-    S.part[kg][i] = ps;
-    __syncthreads();
-    if (tid < CT_TS) {
-      double ssum = 0.0;
-#pragma unroll
-      for (int g = 0; g < 8; ++g) ssum += S.part[g][tid];
-      S.yv[tid] = ssum;
-      a.Y[t.col * CT_TS + tid] = ssum;
-    }
-    __syncthreads();
-    ps = 0.0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) ps = fma(XB[(4 * kg + k) + CT_LD * i], S.yv[4 * kg + k], ps);
-    S.part[kg][i] = ps;
-    __syncthreads();
-    if (tid < CT_TS) {
-      double ssum = 0.0;
-#pragma unroll
-      for (int g = 0; g < 8; ++g) ssum += S.part[g][tid];
-      ct_st_x<DF>(a.Wv + t.col * CT_TS + tid, ssum);
-    }
-  }
   if constexpr (DF) {
     CT_DF_DRAIN();
     if (tid == 0) {
@@ -704,13 +682,31 @@ __global__ __launch_bounds__(256, CT_LEVEL_WAVES) void k_chol_dataflow(CholLevel
   }
 }
 
-// M(I,K) = L(I,K) Linv_K = A(I,K) T_K^-1 for every off-diagonal tile of the factored columns: what the backward
-// substitution multiplies x_I with. One launch over all panels, after the factorisation (A(I,K) is final once K is).
-__global__ __launch_bounds__(256) void k_panel_m(const PanelTask* __restrict__ task, const double* __restrict__ A, const double* __restrict__ Tinv,
-                                                 double* __restrict__ M) {
+// M(I,K) = A(I,K) T_K^-1 for every off-diagonal tile of the factored columns: what the backward substitution multiplies
+// x_I with. One launch over all panels, after the factorisation (A(I,K) is final once K is).  Workgroups [n_panel, ...) form
+// w_J = T_J^-1 r_J of one column each (r_J: the rhs segment the column's finalising workgroup left in Y) - off the
+// critical chain of the factorisation, whose updates use r_J directly.
+__global__ __launch_bounds__(256) void k_panel_m(const PanelTask* __restrict__ task, int n_panel, const double* __restrict__ A, const double* __restrict__ Tinv,
+                                                 double* __restrict__ M, const double* __restrict__ Rv, double* __restrict__ Wv) {
   __shared__ __attribute__((aligned(16))) double XA[CT_TILE_LDS];
   __shared__ __attribute__((aligned(16))) double LI[CT_TILE_LDS];
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, bi = w >> 1, bj = w & 1;
+  if ((int)blockIdx.x >= n_panel) {
+    const int J = (int)blockIdx.x - n_panel, i = tid & 31, kg = tid >> 5;
+    const double* T = Tinv + (int64_t)J * CT_TT;     // symmetric: row i is read as column i (coalesced)
+    double ps = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ps = fma(T[i + CT_TS * (4 * kg + k)], Rv[J * CT_TS + 4 * kg + k], ps);
+    XA[kg * (CT_TS + 1) + i] = ps;
+    __syncthreads();
+    if (tid < CT_TS) {
+      double ssum = 0.0;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) ssum += XA[g * (CT_TS + 1) + tid];
+      Wv[J * CT_TS + tid] = ssum;
+    }
+    return;
+  }
   const PanelTask t = task[blockIdx.x];
   if (t.tile < 0) return;
   const ct_d4 zero = {0.0, 0.0, 0.0, 0.0};
@@ -917,9 +913,9 @@ __global__ void k_diag_rhs(double* __restrict__ A, const int32_t* __restrict__ d
 }
 // start of a solve on one solve set: padded rhs and backward accumulators zeroed, failure flags reset (one launch instead of
 // three memsets)
-__global__ void k_solve_init(double* __restrict__ rhs, double* __restrict__ sv, int npad, int* __restrict__ fail2) {
+__global__ void k_solve_init(double* __restrict__ rhs, double* __restrict__ sv, double* __restrict__ hdiag, int npad, int* __restrict__ fail2) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < npad) { rhs[i] = 0.0; sv[i] = 0.0; }
+  if (i < npad) { rhs[i] = 0.0; sv[i] = 0.0; hdiag[i] = 0.0; }
   if (i < 2) fail2[i] = 0x7f7f7f7f;
 }
 

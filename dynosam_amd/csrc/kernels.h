@@ -1139,7 +1139,7 @@ __global__ void k_assemble_final(AssembleView A, const double* __restrict__ part
 __global__ void k_assemble_final_tiles(AssembleView A, const double* __restrict__ partial, const double* __restrict__ lambda_p,
                                        double add_lambda, const int32_t* __restrict__ off, const int32_t* __restrict__ blk_tile,
                                        double* __restrict__ At, double* __restrict__ raw_int = nullptr, double* __restrict__ raw_sep = nullptr,
-                                       int raw_split = 0) {
+                                       int raw_split = 0, double* __restrict__ hdiag = nullptr) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t blk = t / 36;
   const int el = (int)(t % 36);
@@ -1160,6 +1160,8 @@ __global__ void k_assemble_final_tiles(AssembleView A, const double* __restrict_
   // sharded path: the damping is added later (k_diag_rhs for this rank's interior rows, k_tile_diag after the all-reduce for the
   // separator rows, whose un-reduced diagonal is a sum over ranks and travels with the all-reduce)
   if (dg && ddamp && raw_int) (oa + i >= raw_split ? raw_sep : raw_int)[oa + i] = raw;
+  // magnitude the pivot of this row is measured against when the reduced system is factored (chol_tiles.h: ct_spd_inverse)
+  if (dg && hdiag) hdiag[oa + i] = raw + lm_damp(*lambda_p, ddamp, raw);
   int gi = oa + i, gj = ob + j;
   if (oa < ob) { const int tmp = gi; gi = gj; gj = tmp; }
   const int R0 = oa > ob ? oa : ob, C0 = oa > ob ? ob : oa;

@@ -14,9 +14,14 @@ for rep in range(2):
 b = buf[:nl, :7]
 d = np.diff(b, axis=1)
 print("launches", nl)
-names = ["stage operands", "updates", "re-layout", "potrf", "store L,Linv", "y,w"]
+names = ["stage operands", "updates", "rhs fold, r_K", "SPD inverse", "store T^-1", "tail"]
 ok = (b[:, 0] > 0) & (b[:, 6] > 0)
 for k, n in enumerate(names):
     print(f"  {n:16s} median {np.median(d[ok, k]):9.0f} ticks   min {d[ok, k].min():7d} max {d[ok, k].max():7d}")
+pb = buf[:nl, 7:14]
+okb = ok & (pb[:, 0] > 0)
+if okb.any():
+    edges = np.concatenate([b[okb, 3:4], pb[okb], b[okb, 4:5]], axis=1)
+    print("  pivot blocks 0..7 (median ticks):", " ".join(f"{v:.0f}" for v in np.median(np.diff(edges, axis=1), axis=0)))
 print("  total median", np.median(b[ok, 6] - b[ok, 0]), "ticks;  launch-to-launch median", np.median(np.diff(b[ok, 0])))
 ctx.close()

@@ -74,3 +74,25 @@ def test_real_fixture_through_the_wire_format_builds_the_same_graph(tmp_path):
     assert np.array_equal(g1.var_keys, g2.var_keys) and np.array_equal(g1.var_state, g2.var_state) and g1.n_factors == g2.n_factors > 0
     for a, b in zip(g1.blocks, g2.blocks):
         assert a.type == b.type and np.array_equal(a.slot, b.slot) and np.array_equal(a.var_idx, b.var_idx) and np.array_equal(a.meas, b.meas)
+
+
+def test_pose_only_objects_carry_no_motion_and_version_1_files_still_read(tmp_path):
+    """format version 2: an object record says whether it holds a motion (version 1 wrote an identity H for a pose-only
+    object, which a reader could not tell from a real frontend motion); a version-1 file is still read"""
+    import struct
+    rng = np.random.default_rng(1)
+    pose = lambda: np.concatenate([np.linalg.qr(rng.normal(size=(3, 3)))[0].reshape(-1), rng.normal(size=3)])
+    p = TIO.TrackPacket(3, 0.5, pose(), pose(), {2: pose()}, {2: pose(), 5: pose()}, np.zeros((0, 6)), np.zeros((0, 7)))
+    path = str(tmp_path / "v2.dytr")
+    TIO.write_tracks(path, [p])
+    (b,) = list(TIO.read_tracks(path))
+    assert sorted(b.motions) == [2] and sorted(b.object_poses) == [2, 5] and np.array_equal(b.object_poses[5], p.object_poses[5])
+    assert TIO.to_frame_packet(b).motions.keys() == {2}
+    # the same frame written by hand in the version-1 layout (id | H | has_pose | L)
+    path1 = str(tmp_path / "v1.dytr")
+    with open(path1, "wb") as f:
+        f.write(b"DYTR" + struct.pack("<III", 1, 1, 0) + struct.pack("<qd", 3, 0.5) + p.X_world.astype("<f8").tobytes() + b"\x01" + p.T_k_1_k.astype("<f8").tobytes())
+        f.write(struct.pack("<I", 1) + struct.pack("<i", 2) + p.motions[2].astype("<f8").tobytes() + b"\x01" + p.object_poses[2].astype("<f8").tobytes())
+        f.write(struct.pack("<I", 0) + struct.pack("<I", 0))
+    (c,) = list(TIO.read_tracks(path1))
+    assert np.array_equal(c.motions[2], p.motions[2]) and np.array_equal(c.object_poses[2], p.object_poses[2])

@@ -12,6 +12,13 @@ Follows, line by line where the logic is order dependent:
                                    box, box of the tracks) < min_dynamic_mask_iou
   dynosam/src/frontend/anms/anms.cc:278-361   anms::RangeTree (brute-force square queries instead of the range tree)
   dynosam/src/frontend/anms/NonMaximumSupression.cc:33-56   the response sort in front of it
+  dynosam/src/frontend/vision/StaticFeatureTracker.cc
+      :244-300   trackStatic       first frame -> detectFeatures, else trackPoints           (track_static_frame below)
+      :420-637   trackPoints       LK + flow-back (klt_oracle), RANSAC homography (ransac_oracle), usable / age tests,
+                                   outliers, top-up below min_features_per_frame
+      :330-418   detectFeatures    detection mask (caller mask & background & discs), SparseFeatureDetector::detect
+                                   (FeatureDetector.cc:186-241: CLAHE -> corners -> ANMS -> cornerSubPix: clahe_oracle, gftt_oracle,
+                                   anms_range_tree above, subpix_oracle), contained / shrunken / background tests, new ids
 Undefined in the reference and fixed here (and in the product): the candidate order inside an object (a tbb::parallel_for over
 rows fills the vectors; all responses are equal) = row-major; num_ret <= 0 -> nothing, num_ret == 1 -> the first keypoint (the
 reference divides by num_ret - 1 / num_ret).  PARITY UNPINNED against the binary (the reference has no test for any of this).
@@ -246,7 +253,14 @@ def track_dynamic_klt_frame(prev_dynamic, prev_gray, gray, motion_mask, boundary
       :774-861  per object to sample: goodFeaturesToTrack(mono, 50, 0.01, min_distance, (mask == object) & detection mask),
                 ANMS RangeTree to max_features - num_track (tolerance 0.01), new features of age 0 inside the shrunken image
     prev_dynamic: None or dict(tracklet_id, kp, age, object_id) of frame k-1; gray images uint8.
-    Undefined in the reference and fixed here (and in the product): objects are sampled in ascending id (the reference fills a
+      dynosam/src/frontend/vision/StaticFeatureTracker.cc
+      :244-300   trackStatic       first frame -> detectFeatures, else trackPoints           (track_static_frame below)
+      :420-637   trackPoints       LK + flow-back (klt_oracle), RANSAC homography (ransac_oracle), usable / age tests,
+                                   outliers, top-up below min_features_per_frame
+      :330-418   detectFeatures    detection mask (caller mask & background & discs), SparseFeatureDetector::detect
+                                   (FeatureDetector.cc:186-241: CLAHE -> corners -> ANMS -> cornerSubPix: clahe_oracle, gftt_oracle,
+                                   anms_range_tree above, subpix_oracle), contained / shrunken / background tests, new ids
+Undefined in the reference and fixed here (and in the product): objects are sampled in ascending id (the reference fills a
     tbb::concurrent_unordered_map), corners keep the detector's order through the response sort (all responses are equal), a tracked
     point outside the image is dropped (the reference indexes the mask out of bounds).  The features of frame k carry no flow in this
     mode (the reference writes kp_k - kp_{k-1} into the PREVIOUS frame's feature).  PARITY UNPINNED against the binary."""
@@ -317,3 +331,76 @@ def track_dynamic_klt_frame(prev_dynamic, prev_gray, gray, motion_mask, boundary
     out = dict(tracklet_id=np.array(feats["tracklet_id"], np.int64), kp=np.array(feats["kp"], np.float64).reshape(-1, 2), age=np.array(feats["age"], np.int64),
                object_id=np.array(feats["object_id"], np.int32))
     return out, to_sample, status, tid
+
+
+# ---- the static half of FeatureTracker::track: KltFeatureTracker::trackStatic composed from the per-stage oracles ----
+def _usable_static(kp, motion_mask, shrink_row=0, shrink_col=0):
+    h, w = motion_mask.shape
+    ok = (kp[:, 0] >= 0) & (kp[:, 0] < w) & (kp[:, 1] >= 0) & (kp[:, 1] < h)
+    ok &= (kp[:, 1] >= shrink_row) & (kp[:, 1] < h - shrink_row) & (kp[:, 0] >= shrink_col) & (kp[:, 0] < w - shrink_col)
+    x, y = np.floor(kp[:, 0]).astype(int), np.floor(kp[:, 1]).astype(int)
+    ok[ok] &= motion_mask[y[ok], x[ok]] == 0
+    return ok
+
+
+def detect_static_features(gray, motion_mask, current, detection_mask, next_tracklet_id, max_features=400, max_before_anms=2000, quality_level=0.001,
+                           min_distance=8, shrink_row=0, shrink_col=0, use_anms=True, use_clahe=True, use_subpix=True):
+    """KltFeatureTracker::detectFeatures. current: dict(tracklet_id, kp [n,2] f64, age). returns (dict, next id)"""
+    from . import clahe_oracle as CO, gftt_oracle as GO, subpix_oracle as SO
+    mask = np.full(motion_mask.shape, 255, np.uint8) if detection_mask is None else np.array(detection_mask, np.uint8)
+    mask[motion_mask != 0] = 0
+    for x, y in current["kp"]:
+        # cv::circle(..., cv::Point2f(kp(0), kp(1)), ...): Point2f -> Point = saturate_cast<int> (to nearest, ties to even)
+        _disc(mask, int(np.rint(np.float32(x))), int(np.rint(np.float32(y))), min_distance, 0)
+    want = max_features - len(current["tracklet_id"])
+    if want <= 0:
+        return current, next_tracklet_id
+    img = CO.clahe(gray) if use_clahe else gray
+    c, _ = GO.good_features_to_track(img, mask, max_before_anms, quality_level, float(min_distance))
+    if use_anms:
+        c = c[anms_range_tree(c, want, 0.1, motion_mask.shape[1], motion_mask.shape[0])]
+    if use_subpix and len(c):
+        c, _ = SO.corner_sub_pix(img, c)
+    c = c.astype(np.float64).reshape(-1, 2)
+    c = c[_usable_static(c, motion_mask, shrink_row, shrink_col)]
+    if not use_anms:
+        c = c[:want]
+    ids = next_tracklet_id + np.arange(len(c), dtype=np.int64)
+    out = dict(tracklet_id=np.concatenate([current["tracklet_id"], ids]), kp=np.concatenate([current["kp"].reshape(-1, 2), c]),
+               age=np.concatenate([current["age"], np.zeros(len(c), np.int64)]))
+    return out, next_tracklet_id + len(c)
+
+
+def track_static_frame(previous, prev_gray, gray, motion_mask, detection_mask, next_tracklet_id, max_features=400, min_features=200, max_age=25,
+                       max_before_anms=2000, quality_level=0.001, min_distance=8, shrink_row=0, shrink_col=0, use_anms=True, use_clahe=True,
+                       use_subpix=True, geometric_verification=True, ransac_threshold=5.0):
+    """KltFeatureTracker::trackStatic. previous: None or dict(tracklet_id, kp, age). returns (features dict, outlier ids, info dict, next id)"""
+    from . import klt_oracle as KO, ransac_oracle as RO
+    kw = dict(max_features=max_features, max_before_anms=max_before_anms, quality_level=quality_level, min_distance=min_distance, shrink_row=shrink_row,
+              shrink_col=shrink_col, use_anms=use_anms, use_clahe=use_clahe, use_subpix=use_subpix)
+    info = dict(static_track_optical_flow=0, static_track_detections=0, new_static_detections=False, static_track_ransac_rejected=0)
+    empty = dict(tracklet_id=np.zeros(0, np.int64), kp=np.zeros((0, 2)), age=np.zeros(0, np.int64))
+    if previous is None or len(previous["tracklet_id"]) == 0:
+        out, nid = detect_static_features(gray, motion_mask, empty, detection_mask, next_tracklet_id, **kw)
+        info["static_track_detections"] = len(out["tracklet_id"])
+        return out, np.zeros(0, np.int64), info, nid
+    prev_kp = previous["kp"].astype(np.float32)
+    cur, _back, good, _st = KO.track_points(prev_gray, gray, prev_kp)
+    good = good.astype(bool)
+    if geometric_verification and good.any():
+        gi = np.nonzero(good)[0]
+        inl, _best, _H = RO.verify_homography(prev_kp[gi], cur[gi], ransac_threshold)
+        good[gi[inl == 0]] = False
+        info["static_track_ransac_rejected"] = int((inl == 0).sum())
+    outliers = previous["tracklet_id"][~good]
+    kp = cur.astype(np.float64)
+    keep = good & _usable_static(kp, motion_mask, shrink_row, shrink_col) & (previous["age"] + 1 <= max_age)
+    tracked = dict(tracklet_id=previous["tracklet_id"][keep], kp=kp[keep], age=previous["age"][keep] + 1)
+    info["static_track_optical_flow"] = int(keep.sum())
+    nid = next_tracklet_id
+    if len(tracked["tracklet_id"]) < min_features:
+        n0 = len(tracked["tracklet_id"])
+        tracked, nid = detect_static_features(gray, motion_mask, tracked, detection_mask, nid, **kw)
+        info["new_static_detections"] = True
+        info["static_track_detections"] = len(tracked["tracklet_id"]) - n0
+    return tracked, outliers, info, nid

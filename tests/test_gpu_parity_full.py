@@ -63,6 +63,61 @@ def test_config2_full_convergence_matches_oracle(oracle):
     c.close()
 
 
+def _tight():
+    from dynosam_amd.optimizer import LevenbergMarquardtParams
+    P = LevenbergMarquardtParams()
+    P.relative_error_tol = 1e-12
+    P.absolute_error_tol = 1e-12
+    P.max_iterations = 400
+    return P
+
+
+@pytest.mark.parametrize("k", [10, 25])
+def test_config2_values_track_the_oracle_iteration_by_iteration(oracle, k):
+    """Values with NO slack term: stop both optimisers after the same k outer iterations (identical accept / reject traces) and
+    compare where they are.  Every damped solve agrees to ~1e-6 relative (cond(H) ~ 1e12: the sigma = 1e-6 gauge prior) and the
+    estimate travels 68 m, so the differences add up along the way: measured 1.3e-5 max(1, |x|) at k = 10 and 4.0e-5 at k = 25
+    (scripts/dbg_tight.py); the bound is 1e-4.  (Running config 2 "into the minimiser" is not available as a test: with
+    relativeErrorTol = absoluteErrorTol = 1e-12 GTSAM's lambda schedule is still crawling along the weak directions after 226
+    outer iterations - a Gauss-Newton step of 8e-3 is left, the cost changes by 1e-9 per iteration - see the well-conditioned
+    graphs below for that comparison.)"""
+    from dynosam_amd.optimizer import Context, LevenbergMarquardtParams
+    g = synth.make_hybrid_graph(synth.config(2))
+    P = LevenbergMarquardtParams()
+    P.max_iterations = k
+    P.relative_error_tol = 1e-300
+    P.absolute_error_tol = 0.0
+    og = oracle.OracleGraph(g)
+    ro, _ = og.optimize(P)
+    c = Context(); c.upload(g)
+    r = c.optimize(P)
+    assert trace(r) == trace(ro) and r.iterations == ro.iterations == k and r.inner_iterations == ro.inner_iterations
+    assert abs(r.error_after - ro.error_after) <= 1e-6 * ro.error_after
+    v, vo = c.values(), og.state()
+    assert (np.abs(v - vo) <= 1e-4 * np.maximum(1.0, np.abs(vo))).all(), float((np.abs(v - vo) / np.maximum(1.0, np.abs(vo))).max())
+    c.close()
+
+
+@pytest.mark.parametrize("kind", ["hybrid", "wcme"])
+def test_tight_convergence_values_match_oracle(oracle, kind):
+    """relativeErrorTol = absoluteErrorTol = 1e-12 on graphs whose minimiser LM does reach (config 1 HYBRID; a 40-frame WCME graph):
+    up to 400 outer iterations with the same accept / reject trace, the same counts, the final cost to 1e-12 and the VALUES to
+    1e-7 max(1, |x|) (measured 8.6e-9 / 1.2e-11) - no term for what the optimiser leaves un-done."""
+    from dynosam_amd.optimizer import Context
+    g = synth.make_hybrid_graph(synth.config(1)) if kind == "hybrid" else \
+        synth.make_wcme_graph(synth.config(1, frames=40, objects=2, static_points=200, dynamic_points_per_object=40))
+    P = _tight()
+    og = oracle.OracleGraph(g)
+    ro, _ = og.optimize(P)
+    c = Context(); c.upload(g)
+    r = c.optimize(P)
+    assert trace(r) == trace(ro) and r.iterations == ro.iterations and r.inner_iterations == ro.inner_iterations
+    assert abs(r.error_after - ro.error_after) <= 1e-12 * ro.error_after
+    v, vo = c.values(), og.state()
+    assert (np.abs(v - vo) <= 1e-7 * np.maximum(1.0, np.abs(vo))).all(), float((np.abs(v - vo) / np.maximum(1.0, np.abs(vo))).max())
+    c.close()
+
+
 @pytest.fixture(scope="module")
 def config5(oracle):
     from dynosam_amd.optimizer import LevenbergMarquardtParams

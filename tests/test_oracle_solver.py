@@ -118,3 +118,27 @@ def test_diagonal_damping_dense_equals_schur_and_changes_the_search():
     assert out[False, 1][:2] == out[True, 1][:2] and abs(out[False, 1][2] - out[True, 1][2]) <= 1e-9 * out[True, 1][2]
     assert out[False, 0][:2] == out[True, 0][:2]
     assert out[False, 1][2] != out[False, 0][2]
+
+
+def test_frozen_linearisation_lm_of_the_oracle(oracle):
+    """orc_lm_optimize with relinearize_threshold (the checker of SURVEY 8 f4): a threshold nothing stays under is the plain LM
+    bit for bit; at 1e-2 a good part of the factor linearisations is reused, the reported cost is the true cost of the values,
+    and the optimiser ends near the fully relinearised optimum"""
+    from dynosam_amd import synth
+    g = synth.make_hybrid_graph(synth.config(1, frames=16, static_points=80, dynamic_points_per_object=20, seed=4))
+    og = oracle.OracleGraph(g)
+    r0, _ = og.optimize()
+    v0 = og.state()
+    P = oracle.default_params()
+    P.relinearize_threshold = 1e-300
+    og.set_state(g.var_state)
+    r1, _ = og.optimize(P)
+    assert r1.iterations == r0.iterations and r1.error_after == r0.error_after and np.array_equal(og.state(), v0)
+    assert r1.factors_reused <= r1.factors_linearized // 50          # (only factors none of whose variables moved at all)
+    P.relinearize_threshold = 1e-2
+    og.set_state(g.var_state)
+    r2, _ = og.optimize(P)
+    tot = r2.factors_linearized + r2.factors_reused
+    assert tot % g.n_factors == 0 and r2.factors_reused > 0.1 * tot and r2.variables_relinearized < r1.variables_relinearized
+    assert abs(og.error() - r2.error_after) <= 1e-12 * r2.error_after
+    assert r2.error_after - r0.error_after <= 1e-3 * r0.error_before      # (stale points stop the LM a little earlier: 0.21 vs 0.17 from 500)

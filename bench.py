@@ -134,7 +134,15 @@ def main():
             collective_kind = f"torch.distributed {args.backend} callback (blocking)"
 
     ctx.set_profiling(True)   # per-segment HIP-event times for the roofline block (costs the one-graph replay, ~2 %)
+    # time to solution, reported next to the steady-state iteration rate: the FIRST upload of the graph on this
+    # context (host structure analysis + device allocations + H2D), a second upload of the same graph (structure hit: only the numbers
+    # travel) and - measured after the timed region below - upload + LM to GTSAM's default convergence as one wall time
+    t_up = time.perf_counter()
     ctx.upload(shard)
+    upload_ms = 1e3 * (time.perf_counter() - t_up)
+    t_up = time.perf_counter()
+    ctx.upload(shard)
+    upload_hit_ms = 1e3 * (time.perf_counter() - t_up)
 
     def run(n_iter):
         ctx.set_values(g.var_state)
@@ -163,6 +171,15 @@ def main():
     dt = float(tmax.item())
     steps_done = int(rep.iterations)
     stats = ctx.kernel_stats()
+    # drop-in optimize(): upload + LM to default convergence (what one LevenbergMarquardtOptimizer(graph, values).optimize() costs)
+    ctx.set_profiling(False)
+    sync()
+    t_sol = time.perf_counter()
+    ctx.upload(shard)
+    ctx.set_values(g.var_state)
+    rep_full = ctx.optimize(LevenbergMarquardtParams())
+    sync()
+    optimize_wall_ms = 1e3 * (time.perf_counter() - t_sol)
 
     out = None
     if rank == 0:
@@ -180,6 +197,7 @@ def main():
                         peak=HBM_PEAK_GBS, unit="GB/s", traffic=None, avg_launch_us=avg_s * 1e6, launches=dom["launches"])
         roof["frac"] = roof["achieved"] / roof["peak"]
         roof["traffic"] = pmc_traffic(roof["kernel"])
+        roof["traffic_source"] = "committed rocprofv3 --pmc passes under profiles/ (FETCH_SIZE x2 + WRITE_SIZE, per launch); not measured in this run"
         # SURVEY.md 8(d)'s whole-iteration view: algorithmic bytes of one outer iteration (one linearisation + its linear
         # solves' Schur assembly, the HBM-bound stages) over the iteration time, against the HBM peak
         by = {s["name"]: s for s in stats}
@@ -202,10 +220,14 @@ def main():
                        "lambda_search": {"solves_queued": int(rep.solves_queued), "solves_used": int(rep.solves_used),
                                          "speculative_queued": int(rep.spec_queued), "speculative_used": int(rep.spec_used)}},
             "roofline": roof,
+            "time_to_solution": {"upload_ms_cold": upload_ms, "upload_ms_structure_hit": upload_hit_ms, "optimize_wall_ms": optimize_wall_ms,
+                                 "optimize_iterations": int(rep_full.iterations), "optimize_inner_iterations": int(rep_full.inner_iterations),
+                                 "note": "cold = first upload on a fresh context (host structure analysis, device allocations, H2D); structure hit = the same graph "
+                                         "uploaded again (numbers only); optimize_wall = structure-hit upload + LM to GTSAM's default convergence, host wall clock"},
             "kernels": [{"name": s["name"], "launches": s["launches"], "total_ms": round(s["total_ms"], 3)} for s in stats],
             "kernels_note": "HIP-event time per launch group on the stream it ran on; up to three solves (the candidate GTSAM tries and the speculative "
                             "next ones) run concurrently on their own streams, so the rows add up to more than the timed region - the additive per-kernel "
-                            "table of the serialised run is profiles/r02_kernel_stats.txt (rocprofv3), the share of discarded speculative solves is "
+                            "table of the serialised run is profiles/r03_kernel_stats.txt (rocprofv3), the share of discarded speculative solves is "
                             "config.lambda_search",
         }
         if not args.no_cpu_baseline and world == 1:
@@ -228,7 +250,7 @@ def main():
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/r02_pmc_hbm.txt: separate
     FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); None if absent."""
-    for name in ("r02_pmc_hbm.txt", "r01_pmc_hbm.txt"):
+    for name in ("r03_pmc_hbm.txt", "r02_pmc_hbm.txt", "r01_pmc_hbm.txt"):
         try:
             for ln in open(os.path.join(ROOT, "profiles", name)):
                 t = ln.split()

@@ -72,7 +72,7 @@ def _tight():
     return P
 
 
-@pytest.mark.parametrize("k", [10, 25])
+@pytest.mark.parametrize("k", [25])
 def test_config2_values_track_the_oracle_iteration_by_iteration(oracle, k):
     """Values with NO slack term: stop both optimisers after the same k outer iterations (identical accept / reject traces) and
     compare where they are.  Every damped solve agrees to ~1e-6 relative (cond(H) ~ 1e12: the sigma = 1e-6 gauge prior) and the
@@ -100,13 +100,16 @@ def test_config2_values_track_the_oracle_iteration_by_iteration(oracle, k):
 
 @pytest.mark.parametrize("kind", ["hybrid", "wcme"])
 def test_tight_convergence_values_match_oracle(oracle, kind):
-    """relativeErrorTol = absoluteErrorTol = 1e-12 on graphs whose minimiser LM does reach (config 1 HYBRID; a 40-frame WCME graph):
-    up to 400 outer iterations with the same accept / reject trace, the same counts, the final cost to 1e-12 and the VALUES to
-    1e-7 max(1, |x|) (measured 8.6e-9 / 1.2e-11) - no term for what the optimiser leaves un-done."""
+    """relativeErrorTol = absoluteErrorTol = 1e-12 on graphs whose minimiser LM does reach (config 1 HYBRID, up to 400 outer
+    iterations; a 14-frame WCME graph, 60 - the oracle solves world-centric graphs densely, 0.2 s per iteration): the same accept /
+    reject trace, the same counts, the final cost to 1e-12 and the VALUES to 1e-7 max(1, |x|) (measured 8.6e-9 / 1.2e-11 on the
+    40-frame WCME graph of scripts/dbg_tight.py) - no term for what the optimiser leaves un-done."""
     from dynosam_amd.optimizer import Context
     g = synth.make_hybrid_graph(synth.config(1)) if kind == "hybrid" else \
-        synth.make_wcme_graph(synth.config(1, frames=40, objects=2, static_points=200, dynamic_points_per_object=40))
+        synth.make_wcme_graph(synth.config(1, frames=14, objects=2, static_points=60, dynamic_points_per_object=12))
     P = _tight()
+    if kind == "wcme":
+        P.max_iterations = 60
     og = oracle.OracleGraph(g)
     ro, _ = og.optimize(P)
     c = Context(); c.upload(g)

@@ -11,7 +11,8 @@
 //                    diagonal targets also carry the rhs segment  r_I -= A(I,K) w_K = P' r_K
 //                    finalize the workgroup applying the LAST update to a diagonal tile inverts it straight from its
 //                             accumulators (look-ahead), see ct_spd_inverse below: only T_K^-1 is ever used
-//   k_panel_m      M(I,K) = A(I,K) T_K^-1 (backward pass operands) and w_K = T_K^-1 r_K, one launch after the factorisation
+//   k_panel_m      w_K = T_K^-1 r_K, one small launch after the factorisation (the panel products M(I,K) = A(I,K) T_K^-1 of the
+//                  backward pass are stored by the diagonal-target updates; the kernel's panel branch serves A/B builds only)
 //   k_back_group   backward substitution, BWD_GROUP levels per launch
 //
 // All arithmetic fp64.  Every reduction has a fixed order: results are run-to-run deterministic.
@@ -287,7 +288,7 @@ struct CholLevelArgs {
   const FwdTask* task;
   const FwdSrc* src;
   double* A;       // tiles of S, updated in place
-  double* L;       // (unused by the tile kernels: the panel products M live in this buffer)
+  double* L;       // panel products M(I,K) = A(I,K) T_K^-1 (same tile ids as A), stored by the diagonal-target updates
   double* Linv;    // (unused by the tile kernels)
   double* rhs;     // [nt*32] right-hand side, updated in place
   double* Y;       // [nt*32] r_K: the rhs segment of column K when it is eliminated (g_K minus every update)
@@ -556,10 +557,15 @@ __device__ __forceinline__ void ct_run_task(const CholLevelArgs& a, const FwdTas
       vb = ct_gld_x<DF>(a.A + (int64_t)sn.aj * CT_TT, tid);
       vl = ct_gld_x<DF>(a.Tinv + (int64_t)sn.k * CT_TT, tid);
       wv = ct_ld_x<DF>(a.Y + sn.k * CT_TS + (tid & 31));
+      const int32_t cur_ai = s.ai;
       s = sn; sn = sn2;
       __syncthreads();
       if (q == 0) CT_STAMP(1);
       const ct_d4 p = ct_mma_abt<false>(XA, LI, bi, bj, lane, zero);   // T^-1 is stored exactly symmetric
+      // P'(I,K) of a DIAGONAL target is the panel product M(I,K) = A(I,K) T_K^-1 the backward substitution multiplies x_I with
+      // (every off-diagonal tile (I,K) of an eliminated column updates the diagonal tile (I,I) exactly once): stored from here,
+      // the separate panel launch after the factorisation is gone
+      if (diag) ct_gstore_frag(a.L + (int64_t)cur_ai * CT_TT, bi, bj, lane, p);
       __syncthreads();                   // every wave has finished LI
       ct_store_frag(LI, bi, bj, lane, p);
       __syncthreads();
@@ -573,7 +579,7 @@ __device__ __forceinline__ void ct_run_task(const CholLevelArgs& a, const FwdTas
       }
     }
     __syncthreads();                     // the operands are no longer read; the partial rhs products are complete
-    if (diag) rhs_fold();
+    if (diag && !(t.kind & FK_FINAL)) rhs_fold();   // (a finalising task folds its last source AFTER the inverse: off the chain)
   }
   CT_STAMP(2);
 
@@ -591,10 +597,12 @@ __device__ __forceinline__ void ct_run_task(const CholLevelArgs& a, const FwdTas
   }
 
   // ---- finalize: T_K^-1 straight from the accumulators (ct_spd_inverse), r_K for the consumers ----
-  if (tid < CT_TS) ct_st_x<DF>(a.Y + t.col * CT_TS + tid, rv);
   CT_STAMP(3);
   const ct_d4 tinv = ct_spd_inverse(acc, XA, tid, t.col * CT_TS, a.hdiag + t.col * CT_TS, a.fail, dbg_on ? a.dbg + 16 * lvl : nullptr);
   CT_STAMP(4);
+  // r_K (nothing needs it before the next launch; S.part is not touched by the inverse, whose panel lives in XA)
+  if (t.nsrc) rhs_fold();
+  if (tid < CT_TS) ct_st_x<DF>(a.Y + t.col * CT_TS + tid, rv);
   {
     // stored exactly symmetric: the lower triangle and its mirror image (the update reads T^-1 as its own transpose)
     double* const Tg = a.Tinv + (int64_t)t.col * CT_TT;

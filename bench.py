@@ -180,6 +180,15 @@ def main():
     rep_full = ctx.optimize(LevenbergMarquardtParams())
     sync()
     optimize_wall_ms = 1e3 * (time.perf_counter() - t_sol)
+    # the first upload of a NEW context once the process is warm (HIP runtime, code objects, allocator): what the host analysis +
+    # device allocations of this library cost, without the one-off start-up of the process that upload_ms_cold contains
+    upload_new_ctx_ms = None
+    if world == 1:
+        c2 = Context(device=local_rank)
+        t_up = time.perf_counter()
+        c2.upload(shard)
+        upload_new_ctx_ms = 1e3 * (time.perf_counter() - t_up)
+        c2.close()
 
     out = None
     if rank == 0:
@@ -220,9 +229,11 @@ def main():
                        "lambda_search": {"solves_queued": int(rep.solves_queued), "solves_used": int(rep.solves_used),
                                          "speculative_queued": int(rep.spec_queued), "speculative_used": int(rep.spec_used)}},
             "roofline": roof,
-            "time_to_solution": {"upload_ms_cold": upload_ms, "upload_ms_structure_hit": upload_hit_ms, "optimize_wall_ms": optimize_wall_ms,
+            "time_to_solution": {"upload_ms_cold": upload_ms, "upload_ms_new_context_warm_process": upload_new_ctx_ms, "upload_ms_structure_hit": upload_hit_ms,
+                                 "optimize_wall_ms": optimize_wall_ms,
                                  "optimize_iterations": int(rep_full.iterations), "optimize_inner_iterations": int(rep_full.inner_iterations),
-                                 "note": "cold = first upload on a fresh context (host structure analysis, device allocations, H2D); structure hit = the same graph "
+                                 "note": "cold = first upload of the process on a fresh context (host structure analysis, device allocations, H2D, plus the process's one-off HIP start-up); "
+                                         "new_context_warm_process = first upload of a second context afterwards; structure hit = the same graph "
                                          "uploaded again (numbers only); optimize_wall = structure-hit upload + LM to GTSAM's default convergence, host wall clock"},
             "kernels": [{"name": s["name"], "launches": s["launches"], "total_ms": round(s["total_ms"], 3)} for s in stats],
             "kernels_note": "HIP-event time per launch group on the stream it ran on; up to three solves (the candidate GTSAM tries and the speculative "

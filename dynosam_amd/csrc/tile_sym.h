@@ -110,6 +110,7 @@ struct TileSym {
   double flops_factor = 0;        // fp64 flops of one numeric factorisation incl. the redundant panel re-derivations
   bool two_phase = false;         // with n_elim >= 0: ALSO schedule the remaining columns as a second phase
   std::vector<int32_t> phase_end; // index into flaunch where each phase's launches end
+  bool want_df = true;
   int n_elim = -1;                // >= 0: PARTIAL factorisation — only tile columns < n_elim are eliminated; the trailing
                                   // tiles are left holding the Schur complement (marginalisation, SlidingWindowOptimization.cc:157-188)
 
@@ -122,8 +123,10 @@ struct TileSym {
   int32_t diag(int J) const { return col_ptr[J]; }
 
   // lower: list of (I,J), I >= J, tiles holding a structural non-zero of S (duplicates allowed)
-  void analyse(int nt_, std::vector<std::pair<int32_t, int32_t>> lower, bool schedule = true, int n_elim_ = -1, bool two_phase_ = false) {
+  // want_df: also build the per-task dependency lists of the dataflow form (k_chol_dataflow); the level launches do not read them
+  void analyse(int nt_, std::vector<std::pair<int32_t, int32_t>> lower, bool schedule = true, int n_elim_ = -1, bool two_phase_ = false, bool want_df_ = true) {
     nt = nt_;
+    want_df = want_df_;
     n_elim = n_elim_;
     two_phase = two_phase_;
     std::vector<std::vector<int32_t>> rows(nt);
@@ -186,9 +189,9 @@ struct TileSym {
       if (f.kind & FK_ROW) { for (int j = 0; j < f.nsrc; ++j) src_seq[f.src0 + j] = tile_need[fsrc[f.src0 + j].ai]++; }
       else task_seq[i] = tile_need[f.tgt]++;
     }
-    df_deps.assign(ftask.size(), DfDeps{});
+    df_deps.assign(want_df ? ftask.size() : 1, DfDeps{});
     df_more.clear();
-    for (size_t i = 0; i < ftask.size(); ++i) {
+    for (size_t i = 0; want_df && i < ftask.size(); ++i) {
       const FwdTask& f = ftask[i];
       std::vector<std::pair<uint32_t, uint32_t>> d;
       auto add = [&](uint32_t word, uint32_t want) {

@@ -10,3 +10,7 @@ for k in range(3):
     t = time.perf_counter(); c.upload(g); print(f"upload {k}: {1e3 * (time.perf_counter() - t):.2f} ms", flush=True)
 t = time.perf_counter(); r = c.optimize(); print(f"optimize to default convergence: {1e3 * (time.perf_counter() - t):.2f} ms, {r.iterations} iterations", flush=True)
 c.close()
+print("--- a second context in the same (now warm) process ---", flush=True)
+c = Context()
+t = time.perf_counter(); c.upload(g); print(f"upload 0 of context 2: {1e3 * (time.perf_counter() - t):.2f} ms", flush=True)
+c.close()

@@ -25,6 +25,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# kernel arguments in device memory (a ROCm runtime setting read when HIP starts up): +0.7 % on the launch-bound level chain
+# (profiles/r03_ab_misc.txt); the caller's own setting wins
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_PEAK_TFLOPS = 78.6   # MI355X fp64 vector/matrix peak

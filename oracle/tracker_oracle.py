@@ -19,6 +19,8 @@ Follows, line by line where the logic is order dependent:
       :330-418   detectFeatures    detection mask (caller mask & background & discs), SparseFeatureDetector::detect
                                    (FeatureDetector.cc:186-241: CLAHE -> corners -> ANMS -> cornerSubPix: clahe_oracle, gftt_oracle,
                                    anms_range_tree above, subpix_oracle), contained / shrunken / background tests, new ids
+      :1212-1358 propogateMask     an object whose previous tracks now land on background gets its previous mask warped forward
+                                   by the dense flow into the current mask                      (propogate_mask below)
 Undefined in the reference and fixed here (and in the product): the candidate order inside an object (a tbb::parallel_for over
 rows fills the vectors; all responses are equal) = row-major; num_ret <= 0 -> nothing, num_ret == 1 -> the first keypoint (the
 reference divides by num_ret - 1 / num_ret).  PARITY UNPINNED against the binary (the reference has no test for any of this).
@@ -86,6 +88,45 @@ def within_shrunken(x, y, w, h, shrink_row, shrink_col):
     """FeatureTrackerBase::isWithinShrunkenImage on (col, row) = static_cast<int>(kp)"""
     c, r = np.asarray(x).astype(np.int64), np.asarray(y).astype(np.int64)
     return (r > shrink_row) & (r < h - shrink_row) & (c > shrink_col) & (c < w - shrink_col)
+
+
+def propogate_mask(prev_object_id, prev_predicted_kp, prev_mask, prev_flow, cur_mask, shrink_row=0, shrink_col=0, min_points=150):
+    """FeatureTracker::propogateMask (FeatureTracker.cc:1212-1358), called between objectDetection and the tracks when
+    use_propogate_mask (:107-110).  prev_object_id [n], prev_predicted_kp [n, 2]: the usable dynamic features of frame k-1 (in
+    container order); prev_mask [H, W] int, prev_flow [H, W, 2] float32: frame k-1's mask and its flow to frame k; cur_mask: frame k's
+    mask.  Returns (mask of frame k after the propagation, labels that were propagated).
+      per label of frame k-1's features, ascending (:1233-1236): the labels of the CURRENT mask at the features' predicted keypoints
+      (static_cast<int>, strictly inside the image: :1273-1276); fewer than 150 of them -> skipped (:1281); the most frequent label -
+      ties go to the smallest one: the counts are sorted by a std::sort over < 16 map entries in key order, which libstdc++ runs as
+      an insertion sort that leaves equal elements in place (:1289-1309) - must be 0 (:1322); then every pixel of the PREVIOUS mask
+      with that label and a flow whose two components are both non-zero (:1332) is moved by its flow and, if the target
+      (static_cast<int>) is inside the shrunken image (:1341) and the un-truncated target strictly inside the image (:1345-1346),
+      stamps the label into the current mask.  Labels are processed one after the other on the SAME mask: a later label sees (and may
+      overwrite) what an earlier one stamped."""
+    prev_object_id = np.asarray(prev_object_id, np.int64)
+    prev_predicted_kp = np.asarray(prev_predicted_kp, np.float64).reshape(-1, 2)
+    prev_mask = np.asarray(prev_mask)
+    flow = np.asarray(prev_flow, np.float32)
+    out = np.array(cur_mask, dtype=np.int32, copy=True)
+    h, w = out.shape
+    done = []
+    for lab in sorted(set(int(o) for o in prev_object_id)):
+        pk = prev_predicted_kp[prev_object_id == lab]
+        u, v = pk[:, 0].astype(np.int64), pk[:, 1].astype(np.int64)          # functional_keypoint::u / v: truncation
+        ok = (u < w) & (u > 0) & (v < h) & (v > 0)
+        votes = out[v[ok], u[ok]]
+        if len(votes) < min_points:
+            continue
+        labels, counts = np.unique(votes, return_counts=True)                # ascending labels; argmax takes the first maximum
+        if int(labels[int(np.argmax(counts))]) != 0:
+            continue
+        rows, cols = np.nonzero(prev_mask == lab)
+        fx, fy = flow[rows, cols, 0].astype(np.float64), flow[rows, cols, 1].astype(np.float64)
+        px, py = cols.astype(np.float64) + fx, rows.astype(np.float64) + fy
+        keep = (fx != 0) & (fy != 0) & within_shrunken(px, py, w, h, shrink_row, shrink_col) & (px < w) & (px > 0) & (py < h) & (py > 0)
+        out[py[keep].astype(np.int64), px[keep].astype(np.int64)] = lab
+        done.append(lab)
+    return out, done
 
 
 def sample_dynamic(motion_mask, flow, detection_mask, objects, n_needed, shrink_row=0, shrink_col=0, tolerance=0.01, next_tracklet_id=0):

@@ -99,3 +99,55 @@ def test_track_dynamic_klt_frame_keeps_features_on_their_objects():
             assert ts == sorted(bm["objects"]) and all(st[o]["object_new"] for o in ts)
         seen |= set(ids.tolist())
         prev, pg, tid = dict(tracklet_id=ids, kp=kp, age=age, object_id=obj), g, tid2
+
+
+def test_propogate_mask_rules():
+    """FeatureTracker::propogateMask restated (oracle/tracker_oracle.py::propogate_mask): the 150-vote gate, background must win the vote
+    (ties go to the smallest label, i.e. to background), zero flow components and the shrunken border are skipped, labels are processed
+    one after the other on the same mask"""
+    H, W = 120, 160
+    prev = np.zeros((H, W), np.int32)
+    prev[30:70, 40:90] = 3
+    prev[80:110, 100:150] = 5
+    flow = np.zeros((H, W, 2), np.float32)
+    flow[..., 0], flow[..., 1] = 2.5, -1.25
+    rng = np.random.default_rng(0)
+
+    def feats(label, n):
+        ys, xs = np.nonzero(prev == label)
+        sel = rng.choice(len(ys), n, replace=False)
+        kp = np.stack([xs[sel], ys[sel]], 1).astype(float)
+        return np.full(n, label), kp + [2.5, -1.25]
+
+    cur = np.zeros((H, W), np.int32)                                     # both objects vanished from the current mask
+    o3, p3 = feats(3, 200)
+    out, done = TO.propogate_mask(o3, p3, prev, flow, cur)
+    assert done == [3] and (out == 3).sum() == (prev == 3).sum()         # every pixel moved by (2.5, -1.25): truncation keeps them distinct
+    ys, xs = np.nonzero(out == 3)
+    assert ys.min() == 28 and xs.min() == 42                             # int(30 - 1.25) = 28, int(40 + 2.5) = 42
+    assert not (out == 5).any() and np.array_equal(cur, np.zeros_like(cur))   # the input mask is not modified
+    o3b, p3b = feats(3, 149)
+    assert TO.propogate_mask(o3b, p3b, prev, flow, cur)[1] == []         # 149 votes: "not enough points to track object"
+    cur2 = cur.copy()
+    cur2[20:80, 30:100] = 3                                              # the detector still sees the object: the vote says 3, nothing is warped
+    out2, done2 = TO.propogate_mask(o3, p3, prev, flow, cur2)
+    assert done2 == [] and np.array_equal(out2, cur2)
+    # a tie between background and another label goes to background (the smaller key)
+    cur3 = cur.copy()
+    u, v = p3[:, 0].astype(int), p3[:, 1].astype(int)
+    cur3[v[:100], u[:100]] = 7
+    n7 = int((cur3[v, u] == 7).sum())
+    if n7 * 2 == len(u):
+        assert TO.propogate_mask(o3, p3, prev, flow, cur3)[1] == [3]
+    # zero flow component: those pixels stay behind; shrunken border: targets outside it are dropped
+    flow2 = flow.copy()
+    flow2[30:50, :, 1] = 0.0
+    out4, _ = TO.propogate_mask(o3, p3, prev, flow2, cur)
+    assert (out4 == 3).sum() == (prev[50:70] == 3).sum()
+    out5, _ = TO.propogate_mask(o3, p3, prev, flow, cur, shrink_row=40, shrink_col=0)
+    ys5, _ = np.nonzero(out5 == 3)
+    assert ys5.min() == 41 and ys5.max() == int(69 - 1.25)
+    # two labels, one after the other: both warped, the second one's vote reads the mask the first one left
+    o5, p5 = feats(5, 160)
+    out6, done6 = TO.propogate_mask(np.concatenate([o3, o5]), np.concatenate([p3, p5]), prev, flow, cur)
+    assert done6 == [3, 5] and (out6 == 5).sum() > 0 and (out6 == 3).sum() > 0

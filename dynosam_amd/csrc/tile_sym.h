@@ -111,6 +111,7 @@ struct TileSym {
   bool two_phase = false;         // with n_elim >= 0: ALSO schedule the remaining columns as a second phase
   std::vector<int32_t> phase_end; // index into flaunch where each phase's launches end
   bool want_df = true;
+  int bitmap_max_nt = 8192;       // structure de-duplication through one bit per tile up to this many tile columns (8 MB), a sort of the list above
   int n_elim = -1;                // >= 0: PARTIAL factorisation — only tile columns < n_elim are eliminated; the trailing
                                   // tiles are left holding the Schur complement (marginalisation, SlidingWindowOptimization.cc:157-188)
 
@@ -130,7 +131,7 @@ struct TileSym {
     n_elim = n_elim_;
     two_phase = two_phase_;
     std::vector<std::vector<int32_t>> rows(nt);
-    if (nt <= 8192) {
+    if (nt <= bitmap_max_nt) {
       // duplicates are the rule (every 6x6 block of the reduced system names its tile): one bit per tile instead of a sort of the
       // list, then the set bits of each column in ascending row order
       const size_t words = ((size_t)nt + 63) / 64;

@@ -82,6 +82,7 @@ int main(int argc, char** argv) {
   }
   TileSym sym;
   if (getenv("TS_ROW_MIN")) sym.row_min_tasks = atoi(getenv("TS_ROW_MIN"));   // force row tasks in narrow levels too
+  if (getenv("TS_BITMAP_MAX")) sym.bitmap_max_nt = atoi(getenv("TS_BITMAP_MAX"));   // 0: the sort path of very large systems
   const int nel = getenv("TS_NELIM") ? atoi(getenv("TS_NELIM")) : -1;   // two-phase schedule: must still solve the whole system
   sym.analyse(nt, lower, true, nel < 0 ? -1 : std::min(nel, nt), nel >= 0);
   // tile buffers

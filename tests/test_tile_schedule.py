@@ -48,3 +48,15 @@ def test_row_tasks_solve_the_system(checker):
         assert float(kv["residual"]) < 1e-10
         plain = run(checker, *args)
         assert float(kv["fwd_tasks"]) < 0.9 * plain["fwd_tasks"]       # and they really are fewer, fatter tasks (0.4x on the wide band)
+
+
+def test_sorted_and_bitmap_structure_agree(checker):
+    """the tile structure is de-duplicated through a bit per tile up to 8192 tile columns and by a sort of the list above; both give
+    the same schedule (levels, stored tiles, tasks) and solve the system"""
+    for args in ((200, 14, 1, 2), (1200, 84, 1, 7, 0, 560), (37, 3, 1, 3, 10)):
+        a = run(checker, *args)
+        out = subprocess.run([checker, *map(str, args)], capture_output=True, text=True, timeout=300, env=dict(os.environ, TS_BITMAP_MAX="0"))
+        assert out.returncode == 0, out.stdout + out.stderr
+        b = {k: float(v) for k, v in (tok.split("=") for tok in out.stdout.split() if "=" in tok)}
+        assert b["residual"] < 1e-10
+        assert {k: v for k, v in a.items() if k != "residual"} == {k: v for k, v in b.items() if k != "residual"}

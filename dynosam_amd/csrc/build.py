@@ -6,8 +6,8 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = ["dynogfx.hip", "dynoflow.hip", "dynowindow.hip", "dynotracker.hip", "dynoformulation.hip"]
-DEPS = ["dynogfx.hip", "dynoflow.hip", "dynowindow.hip", "dynotracker.hip", "dynoformulation.hip", os.path.join("..", "..", "include", "dynoflow.h"), "kernels.h", "chol_tiles.h", "tile_sym.h", "dev_factors.h", "dev_se3.h", "motion_refine.h", os.path.join("..", "..", "include", "dynogfx.h")]
+SRC = ["dynogfx.hip", "dynoflow.hip", "dynowindow.hip", "dynosmoother.hip", "dynoparallel.hip", "dynotracker.hip", "dynoformulation.hip"]
+DEPS = ["dynogfx.hip", "dynoflow.hip", "dynowindow.hip", "dynosmoother.hip", "window_host.h", "formulation_internal.h", "dynotracker.hip", "dynoformulation.hip", os.path.join("..", "..", "include", "dynoflow.h"), "kernels.h", "chol_tiles.h", "tile_sym.h", "dev_factors.h", "dev_se3.h", "motion_refine.h", os.path.join("..", "..", "include", "dynogfx.h")]
 OUT = os.path.join(HERE, "libdynogfx.so")
 
 

@@ -142,9 +142,11 @@ class NonlinearFactorGraph {
   size_t size() const { return f.size(); }
   const NonlinearFactor::shared_ptr& operator[](size_t i) const { return f[i]; }
   template <class F> void add(const F& x) { f.push_back(std::make_shared<F>(x)); }
+  void push_back(const NonlinearFactor::shared_ptr& x) { f.push_back(x); }
  private:
   std::vector<NonlinearFactor::shared_ptr> f;
 };
+typedef std::vector<size_t> FactorIndices;   // gtsam/inference/Factor.h (FastVector<FactorIndex>)
 struct LevenbergMarquardtParams {
   size_t maxIterations = 100; double relativeErrorTol = 1e-5, absoluteErrorTol = 1e-5, errorTol = 0, lambdaInitial = 1e-5, lambdaFactor = 10, lambdaUpperBound = 1e5,
          lambdaLowerBound = 0, minModelFidelity = 1e-3; bool diagonalDamping = false, useFixedLambdaFactor = true;

@@ -105,14 +105,18 @@ class KltFeatureTracker:
         return StaticFeatures(np.concatenate([current.tracklet_id, ids]), np.concatenate([current.kp, c]),
                               np.concatenate([current.age, np.zeros(len(c), np.int64)]))
 
-    def track_static(self, previous: StaticFeatures | None, motion_mask_cur, detection_mask=None, init_pts=None, frame_slot=1):
+    def track_static(self, previous: StaticFeatures | None, motion_mask_cur, detection_mask=None, init_pts=None, frame_slot=1, R_km1_k=None, K=None):
         """returns (features of the current frame, tracklet ids of `previous` that became outliers).  frame_slot: where the CURRENT
-        image is resident (1: the pair is (previous, current); 0: first frame of a stream uploaded as (current, next))."""
+        image is resident (1: the pair is (previous, current); 0: first frame of a stream uploaded as (current, next)).
+        R_km1_k (+ camera matrix K): the predicted rotation of FeatureTracker::track (FeatureTracker.hpp:68-70) - the LK then starts
+        from predictKeypointsGivenRotation (StaticFeatureTracker.cc:455-466)."""
         self.info = dict(static_track_optical_flow=0, static_track_detections=0, new_static_detections=False, static_track_ransac_rejected=0)
         if previous is None or len(previous) == 0:
             out = self.detect_features(frame_slot, motion_mask_cur, StaticFeatures(), detection_mask)
             self.info["static_track_detections"] = len(out)
             return out, np.zeros(0, np.int64)
+        if R_km1_k is not None and init_pts is None:
+            init_pts = self.t.predict_keypoints_given_rotation(previous.kp.astype(np.float32), R_km1_k, K, self.p.shrink_row, self.p.shrink_col)
         r = self.t.track_points_klt(previous.kp.astype(np.float32), init_pts)
         good = r["status"] == 1
         if self.p.geometric_verification and good.any():

@@ -199,3 +199,77 @@ def track_points(prev_gray, next_gray, prev_pts, init_pts=None, min_success=10):
     dist = np.sqrt((dx * dx + dy * dy).astype(np.float32)).astype(np.float32)
     good = (st != 0) & (rst != 0) & (dist <= np.float32(0.5))
     return cur, back, good.astype(np.uint8), st
+
+
+def _eigen_quat_w(R: np.ndarray) -> float:
+    """w of Eigen::Quaterniond(R) (Eigen/src/Geometry/Quaternion.h, quaternionbase_assign_impl<Mat, 3, 3>), which is what
+    gtsam::Rot3::toQuaternion() returns: t = trace; t > 0: w = 0.5 sqrt(t + 1); else from the largest diagonal entry"""
+    R = np.asarray(R, np.float64).reshape(3, 3)
+    t = R[0, 0] + R[1, 1] + R[2, 2]
+    if t > 0.0:
+        return 0.5 * np.sqrt(t + 1.0)
+    i = 0
+    if R[1, 1] > R[0, 0]:
+        i = 1
+    if R[2, 2] > R[i, i]:
+        i = 2
+    j, k = (i + 1) % 3, (i + 2) % 3
+    tt = np.sqrt(R[i, i] - R[j, j] - R[k, k] + 1.0)
+    return (R[k, j] - R[j, k]) * (0.5 / tt)
+
+
+def _matx33f_mul(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """cv::Matx33f * cv::Matx33f: every entry a float accumulator over k = 0, 1, 2, one rounding per operation"""
+    c = np.zeros((3, 3), np.float32)
+    for i in range(3):
+        for j in range(3):
+            s = np.float32(0)
+            for k in range(3):
+                s = np.float32(s + np.float32(a[i, k] * b[k, j]))
+            c[i, j] = s
+    return c
+
+
+def _eigen_inverse3(m: np.ndarray) -> np.ndarray:
+    """Eigen::Matrix3d::inverse() (Eigen/src/LU/InverseImpl.h, compute_inverse_size3_helper): cyclic cofactors, the determinant along
+    column 0, every entry cofactor * (1 / det)"""
+    def cof(i, j):
+        i1, i2, j1, j2 = (i + 1) % 3, (i + 2) % 3, (j + 1) % 3, (j + 2) % 3
+        return m[i1, j1] * m[i2, j2] - m[i1, j2] * m[i2, j1]
+    det = (cof(0, 0) * m[0, 0] + cof(1, 0) * m[1, 0]) + cof(2, 0) * m[2, 0]
+    inv_det = 1.0 / det
+    out = np.zeros((3, 3))
+    for i in range(3):
+        for j in range(3):
+            out[j, i] = cof(i, j) * inv_det
+    return out
+
+
+def rotation_homography(R_km1_k: np.ndarray, K: np.ndarray) -> np.ndarray:
+    """H = K_cv * R * K_inv_cv of FeatureTrackerBase::predictKeypointsGivenRotation (dynosam/src/frontend/vision/FeatureTrackerBase.cc:63-72):
+    K inverted in double (Eigen), then everything cast to float and multiplied as cv::Matx33f, left to right"""
+    K = np.asarray(K, np.float64).reshape(3, 3)
+    Kf, Rf, Kif = K.astype(np.float32), np.asarray(R_km1_k, np.float64).reshape(3, 3).astype(np.float32), _eigen_inverse3(K).astype(np.float32)
+    return _matx33f_mul(_matx33f_mul(Kf, Rf), Kif)
+
+
+def predict_keypoints_given_rotation(pts_km1: np.ndarray, R_km1_k: np.ndarray, K: np.ndarray, width: int, height: int, shrink_row: int = 0, shrink_col: int = 0) -> np.ndarray:
+    """FeatureTrackerBase::predictKeypointsGivenRotation (FeatureTrackerBase.cc:50-105), float32 as the original: a rotation whose quaternion has
+    |1 - |w|| < 1e-4 copies the points; else p2 = H (x, y, 1), re-homogenised when p2.z > 0 (the previous point otherwise), and kept only if
+    it lies within the shrunken image (isWithinShrunkenImage, :313-326: the coordinates truncated to int) - the previous point otherwise"""
+    pts = np.ascontiguousarray(pts_km1, np.float32).reshape(-1, 2)
+    if abs(1.0 - abs(_eigen_quat_w(R_km1_k))) < 1e-4:
+        return pts.copy()
+    H = rotation_homography(R_km1_k, K)
+    out = pts.copy()
+    one = np.float32(1)
+    for i, (x, y) in enumerate(pts):
+        p2 = [np.float32(np.float32(np.float32(np.float32(H[r, 0] * x) + np.float32(H[r, 1] * y)) + np.float32(H[r, 2] * one))) for r in range(3)]
+        if p2[2] > np.float32(0):
+            nx, ny = np.float32(p2[0] / p2[2]), np.float32(p2[1] / p2[2])
+        else:
+            nx, ny = x, y
+        col, row = int(np.float64(nx)), int(np.float64(ny))          # Keypoint is a double vector; u(), v() assigned to int truncate
+        if row > shrink_row and row < height - shrink_row and col > shrink_col and col < width - shrink_col:
+            out[i] = (nx, ny)
+    return out

@@ -414,7 +414,7 @@ def detect_static_features(gray, motion_mask, current, detection_mask, next_trac
 
 def track_static_frame(previous, prev_gray, gray, motion_mask, detection_mask, next_tracklet_id, max_features=400, min_features=200, max_age=25,
                        max_before_anms=2000, quality_level=0.001, min_distance=8, shrink_row=0, shrink_col=0, use_anms=True, use_clahe=True,
-                       use_subpix=True, geometric_verification=True, ransac_threshold=5.0):
+                       use_subpix=True, geometric_verification=True, ransac_threshold=5.0, R_km1_k=None, K=None):
     """KltFeatureTracker::trackStatic. previous: None or dict(tracklet_id, kp, age). returns (features dict, outlier ids, info dict, next id)"""
     from . import klt_oracle as KO, ransac_oracle as RO
     kw = dict(max_features=max_features, max_before_anms=max_before_anms, quality_level=quality_level, min_distance=min_distance, shrink_row=shrink_row,
@@ -426,7 +426,9 @@ def track_static_frame(previous, prev_gray, gray, motion_mask, detection_mask, n
         info["static_track_detections"] = len(out["tracklet_id"])
         return out, np.zeros(0, np.int64), info, nid
     prev_kp = previous["kp"].astype(np.float32)
-    cur, _back, good, _st = KO.track_points(prev_gray, gray, prev_kp)
+    # the predicted rotation of FeatureTracker::track: LK from predictKeypointsGivenRotation, retried cold below 10 successes (StaticFeatureTracker.cc:455-503)
+    init = None if R_km1_k is None else KO.predict_keypoints_given_rotation(prev_kp, R_km1_k, K, gray.shape[1], gray.shape[0], shrink_row, shrink_col)
+    cur, _back, good, _st = KO.track_points(prev_gray, gray, prev_kp, init)
     good = good.astype(bool)
     if geometric_verification and good.any():
         gi = np.nonzero(good)[0]

@@ -1159,7 +1159,8 @@ __global__ void k_assemble_final_tiles(AssembleView A, const double* __restrict_
   const int oa = off[a], ob = off[b];
   // sharded path: the damping is added later (k_diag_rhs for this rank's interior rows, k_tile_diag after the all-reduce for the
   // separator rows, whose un-reduced diagonal is a sum over ranks and travels with the all-reduce)
-  if (dg && ddamp && raw_int) (oa + i >= raw_split ? raw_sep : raw_int)[oa + i] = raw;
+  // (without diagonalDamping the separator rows' sum still travels: it is the scale of their pivot test, the same on every rank)
+  if (dg && raw_int) (oa + i >= raw_split ? raw_sep : raw_int)[oa + i] = raw;
   // magnitude the pivot of this row is measured against when the reduced system is factored (chol_tiles.h: ct_spd_inverse)
   if (dg && hdiag) hdiag[oa + i] = raw + lm_damp(*lambda_p, ddamp, raw);
   int gi = oa + i, gj = ob + j;

@@ -60,12 +60,25 @@ __device__ __forceinline__ double ct_rsqrt(double x) {
   return fma(r, q, r);
 }
 
-// global tile (column-major 32x32, 8 KB) -> LDS (ld 33); 256 lanes, 16 B per lane per trip
+// Which 16-byte chunk of a tile (column-major 32x32: chunk q = rows 2 (q & 15), + 1 of column q >> 4) lane `tid` stages in its first
+// trip (the second takes q + 256: columns 16..31).  A ds_write_b64 is served 16 contiguous lanes at a time: with tid -> chunk tid those
+// 16 lanes hold rows 0, 2, .. 30 of ONE column, which the swizzle maps two-way onto the 16 bank pairs.  Here a group of 16 lanes takes
+// rows 0..15 (or 16..31) of an even AND the next odd column - 8 chunks each - and the two columns' swizzles put their rows on
+// complementary bank pairs: conflict-free (a wave still reads 1 KB of whole cache lines from global memory).
+__device__ __forceinline__ int ct_chunk(int tid) {
+#if CT_SWZ
+  const int l = tid & 15, grp = tid >> 4;
+  return 16 * (2 * (grp >> 1) + (l >> 3)) + 8 * (grp & 1) + (l & 7);
+#else
+  return tid;
+#endif
+}
+// global tile (column-major 32x32, 8 KB) -> LDS; 256 lanes, 16 B per lane per trip
 __device__ __forceinline__ void ct_g2l(const double* __restrict__ g, double* __restrict__ l, int tid) {
   const double2* g2 = reinterpret_cast<const double2*>(g);
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    const int idx = tid + 256 * h;
+    const int idx = ct_chunk(tid) + 256 * h;
     const double2 v = g2[idx];
     const int e = idx * 2, r = e & 31, c = e >> 5;
     l[ct_ix(r, c)] = v.x;
@@ -76,15 +89,17 @@ __device__ __forceinline__ void ct_g2l(const double* __restrict__ g, double* __r
 struct ct_t2 { double2 a, b; };
 __device__ __forceinline__ ct_t2 ct_gld(const double* __restrict__ g, int tid) {
   const double2* g2 = reinterpret_cast<const double2*>(g);
-  return {g2[tid], g2[tid + 256]};
+  const int q = ct_chunk(tid);
+  return {g2[q], g2[q + 256]};
 }
 __device__ __forceinline__ void ct_lst(double* __restrict__ l, int tid, const ct_t2& v) {
+  const int q = ct_chunk(tid);
   {
-    const int e = tid * 2, r = e & 31, c = e >> 5;
+    const int e = q * 2, r = e & 31, c = e >> 5;
     l[ct_ix(r, c)] = v.a.x; l[ct_ix(r + 1, c)] = v.a.y;
   }
   {
-    const int e = (tid + 256) * 2, r = e & 31, c = e >> 5;
+    const int e = (q + 256) * 2, r = e & 31, c = e >> 5;
     l[ct_ix(r, c)] = v.b.x; l[ct_ix(r + 1, c)] = v.b.y;
   }
 }
@@ -532,6 +547,8 @@ __device__ __forceinline__ double pivot_block(double piv, double* __restrict__ p
   const double q1y = pb[16 + cin + 1];
   const double2 c1b = *reinterpret_cast<const double2*>(pb + 16 + cin + 2), c2b = *reinterpret_cast<const double2*>(pb + 32 + cin + 2);
   const double q3by = pb[48 + cin + 3];
+  // (tried: the first pivot through two v_readlane so that its reciprocal runs under the LDS round trip - the wait for the MFMA result
+  //  in front of a v_readlane is longer than in front of the ds_write: 6.8 k -> 6.9 k ticks per inverse, profiles/r04_inverse_forms.txt)
   const double c00 = c0a.x, q1x = c0a.y, q2ax = c0b.x, q3ax = c0b.y, q2ay = c1b.x, q3ay = c1b.y, q2bx = c2b.x, q3bx = c2b.y;
   const double d0 = c00;
   const double r0 = ct_rcp3(d0);
@@ -753,7 +770,8 @@ __device__ __forceinline__ ct_t2 ct_gld_x(const double* __restrict__ g, int tid)
   if constexpr (!DF) return ct_gld(g, tid);
   else {
     const __amdgpu_buffer_rsrc_t r = ct_rsrc(g);
-    const ct_u4 x = __builtin_amdgcn_raw_buffer_load_b128(r, tid * 16, 0, 16), y = __builtin_amdgcn_raw_buffer_load_b128(r, (tid + 256) * 16, 0, 16);
+    const int q = ct_chunk(tid);
+    const ct_u4 x = __builtin_amdgcn_raw_buffer_load_b128(r, q * 16, 0, 16), y = __builtin_amdgcn_raw_buffer_load_b128(r, (q + 256) * 16, 0, 16);
     ct_t2 o;
     o.a = make_double2(__longlong_as_double(((unsigned long long)x[1] << 32) | x[0]), __longlong_as_double(((unsigned long long)x[3] << 32) | x[2]));
     o.b = make_double2(__longlong_as_double(((unsigned long long)y[1] << 32) | y[0]), __longlong_as_double(((unsigned long long)y[3] << 32) | y[2]));
@@ -1032,7 +1050,8 @@ __device__ __forceinline__ void ct_run_task(const CholLevelArgs& a, const FwdTas
 #endif
       const int lr = lane >> 4, lc = lane & 15;
       CT_STAMP_FIN(4);
-      // stored exactly symmetric: the lower triangle and its mirror image (the update reads T^-1 as its own transpose)
+      // stored exactly symmetric: the lower triangle and its mirror image (the update reads T^-1 as its own transpose).
+      // (tried: into the LDS tile, a barrier, and all four waves store whole 16-byte chunks - 1.3 k ticks instead of 1.1 k)
       double* const Tg = a.Tinv + (int64_t)t.col * CT_TT;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {

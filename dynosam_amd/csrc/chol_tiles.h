@@ -1114,6 +1114,9 @@ __device__ __forceinline__ void ct_run_task(const CholLevelArgs& a, const FwdTas
 #ifndef CT_LEVEL_WAVES
 #define CT_LEVEL_WAVES 3
 #endif
+#ifndef CT_FINAL_PRIO
+#define CT_FINAL_PRIO 0
+#endif
 template <bool DBGK>
 __device__ __forceinline__ void ct_level_body(const CholLevelArgs& a, int task0, int lvl, int n_inline) {
   __shared__ __attribute__((aligned(16))) CtTaskLds S;
@@ -1135,6 +1138,11 @@ __device__ __forceinline__ void ct_level_body(const CholLevelArgs& a, int task0,
     }
   }
   const CholDfSync none{};
+#if CT_FINAL_PRIO
+  // the finalising task of a column is the dependent chain of its level: its waves issue first on the SIMDs they share with update tasks
+  // (of this solve or of another candidate's solve on another stream)
+  if (t.kind & FK_FINAL) __builtin_amdgcn_s_setprio(CT_FINAL_PRIO);
+#endif
   ct_run_task<false, DBGK>(a, t, S, none, 0, lvl, dbg_on, dbg_all);
 }
 __global__ __launch_bounds__(256, CT_LEVEL_WAVES) void k_chol_level(CholLevelArgs a, int task0, int lvl, int n_inline, FwdInline inl) {

@@ -337,6 +337,31 @@ def test_c_example_compiles():
     subprocess.run(["gcc", "-O2", "-Wall", "-Werror", "-std=gnu99", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "backend_loop.c"), "-o", exe, lib,
                     "-Wl,-rpath," + os.path.dirname(lib), "-Wl,--allow-shlib-undefined"], check=True)
     assert os.path.exists(exe)
+    # examples/incremental_loop.c: the incremental mode (smoother + IncrementalInterface::optimize with C callbacks as hooks)
+    exe2 = os.path.join(root, "examples", "incremental_loop")
+    subprocess.run(["gcc", "-O2", "-Wall", "-Werror", "-std=gnu99", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "incremental_loop.c"), "-o", exe2, lib,
+                    "-Wl,-rpath," + os.path.dirname(lib), "-Wl,--allow-shlib-undefined"], check=True)
+    assert os.path.exists(exe2)
+
+
+@pytest.mark.gpu
+def test_c_example_runs_the_incremental_mode(tmp_path):
+    """examples/incremental_loop.c on a DYTR stream: every update succeeds (new objects are recovered through the hooks), old variables
+    leave the smoother, exit code 0"""
+    import subprocess
+    from dynosam_amd import synth
+    test_c_example_compiles()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pk = synth.make_packet_stream(synth.config(2, frames=24, static_points=600, dynamic_points_per_object=30))
+    path = str(tmp_path / "inc.dytr")
+    _write_stream(path, pk)
+    r = subprocess.run([os.path.join(root, "examples", "incremental_loop"), path, "6", "0.01"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    last = r.stdout.strip().splitlines()[-1]
+    assert "24 frames, 24 updates ok" in last, last
+    n_marg = int(last.split("variables marginalised")[0].split(",")[-1].strip())
+    calls = int(last.split(" hook calls")[0].split(",")[-1].strip())
+    assert n_marg > 0 and calls >= 1, last
 
 
 @pytest.mark.gpu

@@ -13,6 +13,16 @@ struct Pose {
   double t[3];
 };
 
+// c ? a : b component by component (v_cndmask: no divergence, no indexed array)
+__device__ __forceinline__ Pose select_pose(bool c, const Pose& a, const Pose& b) {
+  Pose T;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) T.R[i] = c ? a.R[i] : b.R[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) T.t[i] = c ? a.t[i] : b.t[i];
+  return T;
+}
+
 __device__ __forceinline__ Pose load_pose(const double* __restrict__ p) {
   Pose T;
 #pragma unroll

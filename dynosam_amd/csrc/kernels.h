@@ -351,28 +351,31 @@ __global__ void k_apply_dx(BlockView B, RtLayout L, const double* __restrict__ J
 }
 
 // HybridSmoothingFactor: one lane per (factor, variable, tangent component) = 18 lanes per factor.
-__global__ void k_linearize_smooth(BlockView B, const double* __restrict__ poses, double* __restrict__ Jbuf,
+__global__ __launch_bounds__(64) void k_linearize_smooth(BlockView B, const double* __restrict__ poses, double* __restrict__ Jbuf,
                                    double* __restrict__ err_out) {
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t i = gid / 18;
   const int c = (int)(gid % 18), vv = c / 6, j = c % 6;
   if (i >= B.count) return;
   const int32_t* v = B.vidx + i * 3;
-  Pose H[3] = {load_pose(poses + 12 * (int64_t)v[0]), load_pose(poses + 12 * (int64_t)v[1]), load_pose(poses + 12 * (int64_t)v[2])};
+  const Pose H0 = load_pose(poses + 12 * (int64_t)v[0]), H1 = load_pose(poses + 12 * (int64_t)v[1]), H2 = load_pose(poses + 12 * (int64_t)v[2]);
   const Pose Le = load_pose(B.consts + 12 * i);
   const double* sg = B.noise + 6 * i;
   double e[6], rp[6], rm[6];
-  res_smooth(H[0], H[1], H[2], Le, e);
+  res_smooth(H0, H1, H2, Le, e);
   // gtsam::numericalDerivative3x: central difference on the manifold, delta = 1e-5
+  // (the perturbed variable and component are chosen by selects, not by indexing: an array indexed by the lane lives in scratch memory)
   const double delta = 1e-5, factor = 1.0 / (2.0 * delta);
-  double dx[6] = {0, 0, 0, 0, 0, 0};
-  const Pose keep = H[vv];
-  dx[j] = delta;
-  H[vv] = retract(keep, dx);
-  res_smooth(H[0], H[1], H[2], Le, rp);
-  dx[j] = -delta;
-  H[vv] = retract(keep, dx);
-  res_smooth(H[0], H[1], H[2], Le, rm);
+  const Pose keep = select_pose(vv == 0, H0, select_pose(vv == 1, H1, H2));
+  double dx[6];
+#pragma unroll
+  for (int a = 0; a < 6; ++a) dx[a] = a == j ? delta : 0.0;
+  Pose Hq = retract(keep, dx);
+  res_smooth(select_pose(vv == 0, Hq, H0), select_pose(vv == 1, Hq, H1), select_pose(vv == 2, Hq, H2), Le, rp);
+#pragma unroll
+  for (int a = 0; a < 6; ++a) dx[a] = a == j ? -delta : 0.0;
+  Hq = retract(keep, dx);
+  res_smooth(select_pose(vv == 0, Hq, H0), select_pose(vv == 1, Hq, H1), select_pose(vv == 2, Hq, H2), Le, rm);
   double* rec = Jbuf + B.rec0 + i * f_rec(T_SMOOTH);
   // noiseModel::Robust(Huber k) on this class (the reference never robustifies it, a generic ABI caller may): the same
   // sqrt(w) on A and b as every other class (Robust::WhitenSystem), and the Huber loss as the error
@@ -399,7 +402,7 @@ __device__ __forceinline__ void res_numeric(const Pose* P, const double (*pt)[3]
   else res_lps(P[0], P[1], P[2], e);
 }
 template <int T>
-__global__ void k_linearize_numeric(BlockView B, const double* __restrict__ poses, const double* __restrict__ points, double* __restrict__ Jbuf,
+__global__ __launch_bounds__(64) void k_linearize_numeric(BlockView B, const double* __restrict__ poses, const double* __restrict__ points, double* __restrict__ Jbuf,
                                     double* __restrict__ err_out) {
   constexpr int D = f_dim(T), AR = f_arity(T);
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -420,17 +423,30 @@ __global__ void k_linearize_numeric(BlockView B, const double* __restrict__ pose
   double e[D], rp[D], rm[D];
   res_numeric<T>(P, pt, e);
   const double delta = 1e-5, factor = 1.0 / (2.0 * delta);
-  if (f_slot_is_point(T, vv >= AR ? 0 : vv) ) {
-    const double keep = pt[vv][j];
-    pt[vv][j] = keep + delta; res_numeric<T>(P, pt, rp);
-    pt[vv][j] = keep - delta; res_numeric<T>(P, pt, rm);
-    pt[vv][j] = keep;
-  } else {
-    double dx[6] = {0, 0, 0, 0, 0, 0};
-    const Pose keep = P[vv];
-    dx[j] = delta;  P[vv] = retract(keep, dx); res_numeric<T>(P, pt, rp);
-    dx[j] = -delta; P[vv] = retract(keep, dx); res_numeric<T>(P, pt, rm);
-    P[vv] = keep;
+  // perturb component j of variable vv, once up and once down; variable and component are chosen by selects over the statically indexed
+  // slots (arrays indexed by the lane would live in scratch memory)
+#pragma unroll
+  for (int sgn = 0; sgn < 2; ++sgn) {
+    const double dl = sgn ? -delta : delta;
+    Pose Pq[F_MAX_ARITY], keep;
+    double ptq[F_MAX_ARITY][3], dx[6];
+    bool first = true;
+#pragma unroll
+    for (int s = 0; s < AR; ++s)
+      if (!f_slot_is_point(T, s)) { keep = first ? P[s] : select_pose(vv == s, P[s], keep); first = false; }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) dx[a] = a == j ? dl : 0.0;
+    const Pose Hq = retract(keep, dx);   // (of a pose slot; unused when vv names a point)
+#pragma unroll
+    for (int s = 0; s < AR; ++s) {
+      if (f_slot_is_point(T, s)) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) ptq[s][a] = (vv == s && j == a) ? pt[s][a] + dl : pt[s][a];
+      } else {
+        Pq[s] = select_pose(vv == s, Hq, P[s]);
+      }
+    }
+    res_numeric<T>(Pq, ptq, sgn ? rm : rp);
   }
   double col[D], we[D];
 #pragma unroll
@@ -505,7 +521,7 @@ __device__ __forceinline__ void error_body(const BlockView& B, int64_t i, const 
   err_out[B.f0 + i] = loss_from_sq(sq, hk);
 }
 template <int T>
-__global__ void k_error(BlockView B, const double* __restrict__ poses, const double* __restrict__ points,
+__global__ __launch_bounds__(128) void k_error(BlockView B, const double* __restrict__ poses, const double* __restrict__ points,
                         double* __restrict__ err_out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B.count) return;

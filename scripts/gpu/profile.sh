@@ -18,5 +18,5 @@ find $O/prof -name "*.db" | head -1 | xargs -I{} python scripts/rocprof_summary.
 find $O/prof_trk -name "*.db" | head -1 | xargs -I{} python scripts/rocprof_summary.py {} $O/tracker_kernel_stats.txt "rocprofv3 --kernel-trace --stats -- python scripts/prof_tracker.py 100" > /dev/null
 python scripts/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/pmc_hbm.txt > /dev/null
 python scripts/pmc_generic.py k_chol_level $O/pmcsq_SQ_* --out $O/pmc_chol_level.txt > /dev/null
-NOSPEC=1 timeout 200 python scripts/level_times.py > $O/level_times.txt 2>&1
+
 rm -rf $O/prof $O/prof_trk $O/pmc_fetch $O/pmc_write $O/pmcsq_SQ_*/

@@ -12,7 +12,7 @@ The reference's graph, in its insertion order:
 No new device code: the monocular projection factor is the stereo class with zero baseline and a rank-2 square-root
 information diag(1/sigma, 0, 1/sigma) - the middle (right-image) row drops out of the whitened residual, cheirality gives
 2 fx in both remaining rows exactly as GenericProjectionFactor does - and the two points of a tracklet form a chain of length
-2 for the solver.  `optimize` runs one LM per object on the main solver (upload + solve); `optimize_batch` is the
+2 for the solver (point chains).  `optimize` runs one LM per object on the main solver (upload + solve); `optimize_batch` is the
 frontend's path: every object of the frame pair in one launch of k_refine_motion (csrc/motion_refine.h), same decisions.
 Deviation: the reference's re-solve loop calls `values.insert(object_motion_key, initial_motion)` on a Values that already
 holds that key (:445), which throws in GTSAM; here the re-solves continue from the optimised values."""

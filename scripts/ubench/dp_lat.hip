@@ -1,4 +1,4 @@
-// micro-benchmarks behind DESIGN.md's latency model of the diagonal-tile factorisation:
+// micro-benchmarks behind HISTORY.md's (rounds 1-3) latency model of the diagonal-tile factorisation:
 // dependent-chain and issue cost of fp64 FMA / rcp / rsq on one wavefront, accuracy of the raw seeds.
 #include <hip/hip_runtime.h>
 #define HIPIGN(x) (void)(x)

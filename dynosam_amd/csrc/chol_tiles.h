@@ -155,6 +155,24 @@ __device__ __forceinline__ ct_d4 ct_mma_abt(const double* __restrict__ X, const 
   }
   return acc + odd;
 }
+// the same with the A operand already in registers (pa[kk] = -X(16 bi + lc, lr + 4 kk)): a row task multiplies ONE product P' with the column
+// operand of every target - its eight A values per lane are read from LDS once, not once per target
+__device__ __forceinline__ void ct_load_neg_afrag(const double* __restrict__ X, int bi, int lane, double (&pa)[8]) {
+  const int lr = lane >> 4, lc = lane & 15;
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) pa[kk] = -X[ct_ix(16 * bi + lc, lr + 4 * kk)];
+}
+__device__ __forceinline__ ct_d4 ct_mma_ra_bt(const double (&pa)[8], const double* __restrict__ Y, int bj, int lane, ct_d4 acc) {
+  const int lr = lane >> 4, lc = lane & 15;
+  ct_d4 odd = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int kk = 0; kk < 8; kk += 2) {
+    const double b = Y[ct_ix(16 * bj + lc, lr + 4 * kk)], b1 = Y[ct_ix(16 * bj + lc, lr + 4 * (kk + 1))];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[kk], b, acc, 0, 0, 0);
+    odd = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[kk + 1], b1, odd, 0, 0, 0);
+  }
+  return acc + odd;
+}
 __device__ __forceinline__ void ct_store_frag(double* __restrict__ T, int bi, int bj, int lane, ct_d4 acc) {
   const int lr = lane >> 4, lc = lane & 15;
 #pragma unroll
@@ -914,8 +932,10 @@ __device__ __forceinline__ void ct_run_task(const CholLevelArgs& a, const FwdTas
     ct_store_frag(Pt, bi, bj, lane, p);
     __syncthreads();                     // P' published; LI is free from here on
     int cur = t.tgt;
+    double pa[8];
+    ct_load_neg_afrag(Pt, bi, lane, pa);
     for (int i = 0;; ++i) {
-      acc = ct_mma_abt<true>(Pt, (i & 1) ? LI : XB, bi, bj, lane, acc);
+      acc = ct_mma_ra_bt(pa, (i & 1) ? LI : XB, bj, lane, acc);
       ct_gstore_frag_x<DF>(a.A + (int64_t)cur * CT_TT, bi, bj, lane, acc);
       if (i + 1 >= n) break;
       // the other buffer was last read by item i - 1, which every wave finished before the barrier that preceded item i

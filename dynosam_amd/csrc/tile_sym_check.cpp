@@ -72,6 +72,19 @@ int main(int argc, char** argv) {
         lower.push_back({hi / TS, lo / TS});
       }
   };
+  if (mode == 2) {
+    // a star of chains, chains first: `split` chains of equal length, each a band of width bwp, every pose k of a chain also coupled with
+    // poses k - 1, k of the hub chain (the last one) - the shape of a chains-first elimination order (object chains, camera chain last):
+    // the tiles of the hub block collect one update per chain and level
+    const int nc = std::max(1, split), len = np / (nc + 1);
+    for (int c = 0; c <= nc; ++c)
+      for (int k = 0; k < len; ++k) {
+        const int a = c * len + k;
+        for (int b = std::max(c * len, a - bwp); b <= a; ++b) link(a, b);
+        if (c < nc) { link(nc * len + k, a); if (k) link(nc * len + k - 1, a); }
+      }
+    for (int a = (nc + 1) * len; a < np; ++a) link(a, a);
+  } else
   for (int a = 0; a < np; ++a)
     for (int b = std::max(0, a - bwp); b <= a; ++b) link(a, b);
   for (int e = 0; e < extra; ++e) { int a = rng() % np, b = rng() % np; link(std::max(a, b), std::min(a, b)); }
@@ -83,6 +96,7 @@ int main(int argc, char** argv) {
   TileSym sym;
   if (getenv("TS_ROW_MIN")) sym.row_min_tasks = atoi(getenv("TS_ROW_MIN"));   // force row tasks in narrow levels too
   if (getenv("TS_BITMAP_MAX")) sym.bitmap_max_nt = atoi(getenv("TS_BITMAP_MAX"));   // 0: the sort path of very large systems
+  if (getenv("TS_SRC_CAP")) sym.src_cap = atoi(getenv("TS_SRC_CAP"));   // sources a target takes per launch (0: all behind their columns)
   const int nel = getenv("TS_NELIM") ? atoi(getenv("TS_NELIM")) : -1;   // two-phase schedule: must still solve the whole system
   sym.analyse(nt, lower, true, nel < 0 ? -1 : std::min(nel, nt), nel >= 0);
   // tile buffers
@@ -210,6 +224,12 @@ int main(int argc, char** argv) {
     rmax = std::max(rmax, std::fabs(acc - g[i]));
     gmax = std::max(gmax, std::fabs(g[i]));
   }
+  int max_src = 0;
+  for (const FwdTask& t : sym.ftask) if (!(t.kind & FK_ROW)) max_src = std::max(max_src, (int)t.nsrc);
+  long long early_src = 0;   // sources applied in the first quarter of the launches (deferred updates move them to later launches)
+  for (size_t l = 0; l + 1 < sym.flaunch.size() && l < sym.flaunch.size() / 4; ++l)
+    for (int32_t t = sym.flaunch[l]; t < sym.flaunch[l + 1]; ++t) early_src += sym.ftask[t].nsrc;
+  printf("max_src=%d early_src=%lld ", max_src, early_src);
   printf("phases=%zu nt=%d tiles=%lld levels=%d fwd_launches=%zu fwd_tasks=%zu bwd_launches=%zu residual=%.3e %s\n", sym.phase_end.size(), nt, (long long)sym.n_tiles, sym.n_levels,
          sym.flaunch.size() - 1, sym.ftask.size(), sym.blaunch.size(), rmax / gmax, (rmax / gmax < 1e-10) ? "OK" : "FAIL");
   return (rmax / gmax < 1e-10) ? 0 : 1;

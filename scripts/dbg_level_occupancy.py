@@ -42,4 +42,12 @@ for key in list(slots)[:64]:
         c += d; pk = max(pk, c)
 print("peak concurrent workgroups on one CU (first 64 CUs):", pk)
 print("kinds:", {int(k): int((kind == k).sum()) for k in np.unique(kind)}, "mean nsrc", float(nsrc.mean()))
+# the longest tasks of the launch: duration, kind (1 DIAG, 2 FINAL, 4 ROW), sources
+d = en - st
+o = np.argsort(-d)[:12]
+print("longest tasks (ticks, kind, nsrc):", [(int(d[i]), int(kind[i]), int(nsrc[i])) for i in o])
+for k in np.unique(kind):
+    m = kind == k
+    print("kind", int(k), "n", int(m.sum()), "duration median", int(np.median(d[m])), "max", int(d[m].max()), "nsrc median", int(np.median(nsrc[m])), "max", int(nsrc[m].max()),
+          "ticks per source (median)", int(np.median(d[m] / np.maximum(1, nsrc[m]))))
 ctx.close()

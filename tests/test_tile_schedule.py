@@ -60,3 +60,24 @@ def test_sorted_and_bitmap_structure_agree(checker):
         b = {k: float(v) for k, v in (tok.split("=") for tok in out.stdout.split() if "=" in tok)}
         assert b["residual"] < 1e-10
         assert {k: v for k, v in a.items() if k != "residual"} == {k: v for k, v in b.items() if k != "residual"}
+
+
+def test_deferred_updates_solve_the_system(checker):
+    """src_cap: a target takes a bounded number of sources per launch and the rest in later launches, up to the launch that finalises its
+    column (tile_sym.h: build_phase) - same launches, same solution; also across the two phases of a sharded solve and with row tasks.
+    Structure 2 = a star of chains eliminated chains first (ten chains + hub): the hub's tiles collect one update per chain and level"""
+    star = (660, 3, 2, 5, 0, 10)
+    for args, env in ((star, {}), (star, {"TS_NELIM": "40"}), (star, {"TS_ROW_MIN": "0"}), ((1200, 84, 1, 7, 0, 560), {}), ((37, 3, 1, 3, 10), {})):
+        res = {}
+        for cap in (0, 1, 2, 5):
+            out = subprocess.run([checker, *map(str, args)], capture_output=True, text=True, timeout=300, env=dict(os.environ, TS_SRC_CAP=str(cap), **env))
+            assert out.returncode == 0, out.stdout + out.stderr
+            res[cap] = {k: float(v) for k, v in (tok.split("=") for tok in out.stdout.split() if "=" in tok)}
+            assert res[cap]["residual"] < 1e-10
+            assert res[cap]["fwd_launches"] == res[0]["fwd_launches"] and res[cap]["levels"] == res[0]["levels"]
+        if args is star and "TS_NELIM" not in env:
+            assert res[0]["max_src"] >= 3                              # the hub really collects several sources per launch
+            if "TS_ROW_MIN" in env:                                    # every launch counts as wide: a small cap moves sources to later launches
+                assert res[1]["early_src"] < res[0]["early_src"] and res[5]["early_src"] == res[0]["early_src"]
+            else:                                                      # launches with few tasks never put off what has just arrived
+                assert all(res[c]["early_src"] == res[0]["early_src"] and res[c]["max_src"] == res[0]["max_src"] for c in (1, 2, 5))

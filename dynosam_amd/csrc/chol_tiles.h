@@ -728,6 +728,7 @@ struct CholLevelArgs {
   double* Tinv;    // [nt] T_K^-1, symmetric, stored when the diagonal tile is eliminated
   const double* hdiag;   // [nt*32] un-reduced Hessian diagonal (+ damping) of every row: the scale of the pivot test
   double pivot_tol;      // a pivot d of a row with scale h is accepted when d > pivot_tol * h (default CT_PIVOT_TOL; 0: gtsam's d > 0)
+  int32_t scr_col_off;   // scratch tile id + scr_col_off = its rhs segment (tile_sym.h: split tasks); nt - n_tiles
 };
 
 #define CT_STAMP(k) do { if (dbg_on) a.dbg[16 * lvl + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
@@ -963,6 +964,23 @@ __device__ __forceinline__ void ct_run_task(const CholLevelArgs& a, const FwdTas
   const int rt = tid - 192;
   const bool rhs_own = (unsigned)rt < (unsigned)CT_TS;
   if (diag && rhs_own) rv = ct_ld_x<DF>(a.rhs + t.col * CT_TS + rt);
+  // what the other workgroups of a split task left in scratch tiles in the previous launch (tile_sym.h: split_max): added before this
+  // launch's sources, and cleared for the next user of the scratch tile
+  if (t.add0) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int32_t sid = (j ? t.add1 : t.add0) - 1;
+      if (sid < 0) continue;
+      double* const sp = a.A + (int64_t)sid * CT_TT;
+      acc += ct_gload_frag_x<DF>(sp, bi, bj, lane);
+      ct_gstore_frag_x<DF>(sp, bi, bj, lane, zero);
+      if (diag && rhs_own) {
+        double* const rp = a.rhs + (int64_t)(sid + a.scr_col_off) * CT_TS + rt;
+        rv += ct_ld_x<DF>(rp);
+        ct_st_x<DF>(rp, 0.0);
+      }
+    }
+  }
   // rhs segment of a diagonal target: r_I -= A(I,K) w_K = P'(I,K) r_K with the product P' the update forms anyway, so the
   // finalising workgroup of column K only has to leave its final r_K behind (a.Y), not w_K = T_K^-1 r_K
   auto rhs_fold = [&]() {
@@ -1441,9 +1459,10 @@ __global__ void k_diag_rhs(double* __restrict__ A, const int32_t* __restrict__ d
 }
 // start of a solve on one solve set: padded rhs and backward accumulators zeroed, failure flags reset (one launch instead of
 // three memsets)
-__global__ void k_solve_init(double* __restrict__ rhs, double* __restrict__ sv, double* __restrict__ hdiag, int npad, int* __restrict__ fail2) {
+__global__ void k_solve_init(double* __restrict__ rhs, double* __restrict__ sv, double* __restrict__ hdiag, int npad, int nrhs, int* __restrict__ fail2) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < npad) { rhs[i] = 0.0; sv[i] = 0.0; hdiag[i] = 0.0; }
+  if (i < npad) { sv[i] = 0.0; hdiag[i] = 0.0; }
+  for (int k = i; k < nrhs; k += gridDim.x * blockDim.x) rhs[k] = 0.0;   // (nrhs >= npad: + the scratch segments of split tasks)
   if (i < 2) fail2[i] = 0x7f7f7f7f;
 }
 

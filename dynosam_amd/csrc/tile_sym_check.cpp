@@ -96,11 +96,13 @@ int main(int argc, char** argv) {
   TileSym sym;
   if (getenv("TS_ROW_MIN")) sym.row_min_tasks = atoi(getenv("TS_ROW_MIN"));   // force row tasks in narrow levels too
   if (getenv("TS_BITMAP_MAX")) sym.bitmap_max_nt = atoi(getenv("TS_BITMAP_MAX"));   // 0: the sort path of very large systems
+  if (getenv("TS_SPLIT")) sym.split_max = atoi(getenv("TS_SPLIT"));   // several workgroups per target with many sources (scratch tiles)
   if (getenv("TS_SRC_CAP")) sym.src_cap = atoi(getenv("TS_SRC_CAP"));   // sources a target takes per launch (0: all behind their columns)
   const int nel = getenv("TS_NELIM") ? atoi(getenv("TS_NELIM")) : -1;   // two-phase schedule: must still solve the whole system
-  sym.analyse(nt, lower, true, nel < 0 ? -1 : std::min(nel, nt), nel >= 0);
+  sym.analyse(nt, lower, true, nel < 0 ? -1 : std::min(nel, nt), nel >= 0, getenv("TS_SPLIT") == nullptr);   // (split tasks exclude the dataflow form)
   // tile buffers
-  std::vector<double> A((size_t)sym.n_tiles * TT, 0.0), L((size_t)sym.n_tiles * TT, 0.0), Li((size_t)nt * TT), r(g), y(npad), w(npad), s(npad, 0.0), x(npad);
+  std::vector<double> A(((size_t)sym.n_tiles + sym.n_scratch) * TT, 0.0), L((size_t)sym.n_tiles * TT, 0.0), Li((size_t)nt * TT), r(g), y(npad), w(npad), s(npad, 0.0), x(npad);
+  r.resize((size_t)npad + (size_t)sym.n_scratch * TS, 0.0);   // scratch rhs segments of split tasks: columns nt ...
   for (int J = 0; J < nt; ++J)
     for (int32_t t = sym.col_ptr[J]; t < sym.col_ptr[J + 1]; ++t) {
       const int I = sym.row_idx[t];
@@ -136,6 +138,16 @@ int main(int argc, char** argv) {
         continue;
       }
       double* T = &A[(size_t)t.tgt * TT];
+      for (int32_t ad : {t.add0, t.add1}) {   // scratch tiles of a split task of the previous launch: add, clear
+        if (!ad) continue;
+        if (ad - 1 < sym.n_tiles || ad - 1 >= sym.n_tiles + sym.n_scratch) { printf("FAIL: scratch id out of range\n"); return 1; }
+        double* Sc = &A[(size_t)(ad - 1) * TT];
+        for (int e = 0; e < TT; ++e) { T[e] += Sc[e]; Sc[e] = 0.0; }
+        if (t.kind & FK_DIAG) {
+          double* rs = &r[(size_t)(nt + (ad - 1 - sym.n_tiles)) * TS];
+          for (int i = 0; i < TS; ++i) { r[t.col * TS + i] += rs[i]; rs[i] = 0.0; }
+        }
+      }
       for (int32_t q = t.src0; q < t.src0 + t.nsrc; ++q) {
         const FwdSrc& sc = sym.fsrc[q];
         mul_abt(&A[(size_t)sc.ai * TT], &Li[(size_t)sc.k * TT], P.data());
@@ -224,6 +236,9 @@ int main(int argc, char** argv) {
     rmax = std::max(rmax, std::fabs(acc - g[i]));
     gmax = std::max(gmax, std::fabs(g[i]));
   }
+  for (size_t e = (size_t)sym.n_tiles * TT; e < A.size(); ++e) if (A[e] != 0.0) { printf("FAIL: a scratch tile was left behind\n"); return 1; }
+  for (size_t e = (size_t)npad; e < r.size(); ++e) if (r[e] != 0.0) { printf("FAIL: a scratch rhs segment was left behind\n"); return 1; }
+  printf("scratch=%d ", sym.n_scratch);
   int max_src = 0;
   for (const FwdTask& t : sym.ftask) if (!(t.kind & FK_ROW)) max_src = std::max(max_src, (int)t.nsrc);
   long long early_src = 0;   // sources applied in the first quarter of the launches (deferred updates move them to later launches)

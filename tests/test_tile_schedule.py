@@ -81,3 +81,20 @@ def test_deferred_updates_solve_the_system(checker):
                 assert res[1]["early_src"] < res[0]["early_src"] and res[5]["early_src"] == res[0]["early_src"]
             else:                                                      # launches with few tasks never put off what has just arrived
                 assert all(res[c]["early_src"] == res[0]["early_src"] and res[c]["max_src"] == res[0]["max_src"] for c in (1, 2, 5))
+
+
+def test_split_tasks_solve_the_system(checker):
+    """split_max: in a launch with many tasks a target with more sources is updated by up to three workgroups at once - the first in place, the others
+    into zeroed scratch tiles (and scratch rhs segments for a diagonal target) that the target's task of the next launch adds and clears; the
+    checker runs the tasks of a launch in random order and fails when a scratch tile is left non-zero at the end"""
+    for args in ((660, 3, 2, 5, 0, 10), (660, 3, 2, 2, 20, 10), (1320, 2, 2, 9, 30, 10), (1200, 84, 1, 7, 0, 560)):
+        res = {}
+        for sp in (0, 1, 2):
+            out = subprocess.run([checker, *map(str, args)], capture_output=True, text=True, timeout=300, env=dict(os.environ, TS_SPLIT=str(sp), TS_ROW_MIN="0"))
+            assert out.returncode == 0, out.stdout + out.stderr
+            res[sp] = {k: float(v) for k, v in (tok.split("=") for tok in out.stdout.split() if "=" in tok)}
+            assert res[sp]["residual"] < 1e-10
+            assert res[sp]["fwd_launches"] == res[0]["fwd_launches"]
+        assert res[0]["scratch"] == 0
+        if res[0]["max_src"] >= 2:
+            assert res[1]["scratch"] > 0 and res[1]["fwd_tasks"] > res[0]["fwd_tasks"] and res[1]["max_src"] < res[0]["max_src"]

@@ -743,14 +743,18 @@ __device__ __forceinline__ double lm_damp(double lambda, bool diag, double hii) 
 
 __global__ void k_point(PointView P, const double* const* __restrict__ Jpp, const double* __restrict__ lambda_p,
                         double* __restrict__ Cq, double* __restrict__ uq, int* __restrict__ fail_flag) {
-  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // FOUR lanes per point: lane j sums the factors j, j + 4, ... of the point, the partial sums meet in a fixed butterfly, lane 0 factors the
+  // 3x3 block (a lane per point is 160 wavefronts on 1024 SIMDs, each walking ~10 records: 18-20 us at the head of every solve)
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t q = gid >> 2;
+  const int jl = (int)(gid & 3);
   if (q >= P.n_point || (P.chained && P.chained[q])) return;
   const double* __restrict__ Jbuf = *Jpp;
   const double lambda = *lambda_p;
   const bool ddamp = lambda_p[1] != 0.0;
-  const double l0 = ddamp ? 0.0 : lambda;        // (identity damping goes in first, as it always did: same rounding as before)
+  const double l0 = (ddamp || jl) ? 0.0 : lambda;   // (identity damping goes in first, in lane 0's sums)
   double h00 = l0, h01 = 0, h02 = 0, h11 = l0, h12 = 0, h22 = l0, g0 = 0, g1 = 0, g2 = 0;
-  for (int k = P.pf_ptr[q]; k < P.pf_ptr[q + 1]; ++k) {
+  for (int k = P.pf_ptr[q] + jl; k < P.pf_ptr[q + 1]; k += 4) {
     const double* J = Jbuf + P.pf_joff[k];
     const double* b = Jbuf + P.pf_boff[k];
 #pragma unroll
@@ -760,6 +764,13 @@ __global__ void k_point(PointView P, const double* const* __restrict__ Jpp, cons
       g0 += a0 * br; g1 += a1 * br; g2 += a2 * br;
     }
   }
+#pragma unroll
+  for (int m = 1; m < 4; m <<= 1) {   // (the lanes of a quad are adjacent and took the same branches)
+    h00 += __shfl_xor(h00, m, 64); h01 += __shfl_xor(h01, m, 64); h02 += __shfl_xor(h02, m, 64);
+    h11 += __shfl_xor(h11, m, 64); h12 += __shfl_xor(h12, m, 64); h22 += __shfl_xor(h22, m, 64);
+    g0 += __shfl_xor(g0, m, 64); g1 += __shfl_xor(g1, m, 64); g2 += __shfl_xor(g2, m, 64);
+  }
+  if (jl) return;
   if (ddamp) { h00 += lm_damp(lambda, true, h00); h11 += lm_damp(lambda, true, h11); h22 += lm_damp(lambda, true, h22); }
   // Cholesky H = L L^T
   bool ok = h00 > 0.0;
@@ -1610,18 +1621,27 @@ struct PointEdgeView {
   const int32_t* e_pose;
   const uint8_t* chained;  // may be null
 };
+// FOUR lanes per point (lane j takes the edges j, j + 4, ...; the four partial sums meet in a fixed butterfly): with a lane per point the
+// launch was 160 wavefronts on 1024 SIMDs, each walking ~10 edges with two dependent loads per edge - 30-48 us at the end of every solve.
 __global__ void k_backsub_points(PointEdgeView V, const double* __restrict__ Z, const double* __restrict__ Cq,
                                  const double* __restrict__ uq, const double* __restrict__ dpose, double* __restrict__ dpoint) {
-  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t q = gid >> 2;
+  const int j = (int)(gid & 3);
   if (q >= V.n_point) return;
   if (V.chained && V.chained[q] == 2) return;   // kept in the reduced system: its update comes from there (k_rp_scatter)
-  double s0 = uq[3 * q], s1 = uq[3 * q + 1], s2 = uq[3 * q + 2];
-  for (int e = V.qe_ptr[q]; e < V.qe_ptr[q + 1]; ++e) {
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  if (j == 0) { s0 = uq[3 * q]; s1 = uq[3 * q + 1]; s2 = uq[3 * q + 2]; }
+  for (int e = V.qe_ptr[q] + j; e < V.qe_ptr[q + 1]; e += 4) {
     const double* z = Z + 18 * (int64_t)e;
     const double* d = dpose + 6 * (int64_t)V.e_pose[e];
 #pragma unroll
     for (int i = 0; i < 6; ++i) { s0 -= z[i * 3] * d[i]; s1 -= z[i * 3 + 1] * d[i]; s2 -= z[i * 3 + 2] * d[i]; }
   }
+  // (lanes of a quad are adjacent and take the same branches: the whole quad is here)
+  s0 += __shfl_xor(s0, 1, 64); s1 += __shfl_xor(s1, 1, 64); s2 += __shfl_xor(s2, 1, 64);
+  s0 += __shfl_xor(s0, 2, 64); s1 += __shfl_xor(s1, 2, 64); s2 += __shfl_xor(s2, 2, 64);
+  if (j) return;
   if (V.chained && V.chained[q] == 1) {   // k_chain_backsub finishes along the chain
     dpoint[3 * q] = s0; dpoint[3 * q + 1] = s1; dpoint[3 * q + 2] = s2;
     return;

@@ -1015,31 +1015,44 @@ struct EdgeView {
 
 // Z is kept twice: rows in edge order (edges of a point contiguous: back-substitution of the points) and in pose-major
 // order (edges of a pose contiguous: the Schur assembly and the reduced rhs walk them almost sequentially).
-__global__ void k_edge_z(EdgeView E, const double* const* __restrict__ Jpp, const double* __restrict__ Cq, double* __restrict__ Z,
-                         double* __restrict__ Zp) {
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= E.n_edge || E.e_jc[e] < 0) return;   // e_jc < 0: sub-edge of a point chain, written by k_chain_edge
-  const double* __restrict__ Jbuf = *Jpp;
-  double Jc[18];
-  load_jc(Jbuf, E.e_jc[e], Jc);
-  const double* Jp = Jbuf + E.e_jp[e];
-  const double* C = Cq + 6 * (int64_t)E.e_point[e];
-  double M[9];  // Jp * C (C upper triangular)
+// The 18 values of an edge go through LDS (odd stride 19) and leave as rows: a lane that stores its own 18 doubles writes at a stride of 144 bytes,
+// 64 cache lines per store instruction; written row by row the point-major copy Z is one contiguous stream per workgroup and the pose-major copy
+// Zp 144-byte runs.
+__global__ __launch_bounds__(128) void k_edge_z(EdgeView E, const double* const* __restrict__ Jpp, const double* __restrict__ Cq, double* __restrict__ Z,
+                                                double* __restrict__ Zp) {
+  __shared__ double zs[128 * 19];
+  __shared__ int32_t zrow[128];   // pose-major row of the edge; -1: not written here
+  const int64_t e0 = (int64_t)blockIdx.x * 128, e = e0 + threadIdx.x;
+  const bool on = e < E.n_edge && E.e_jc[e] >= 0;   // e_jc < 0: sub-edge of a point chain, written by k_chain_edge
+  zrow[threadIdx.x] = on ? E.e_zpos[e] : -1;
+  if (on) {
+    const double* __restrict__ Jbuf = *Jpp;
+    double Jc[18];
+    load_jc(Jbuf, E.e_jc[e], Jc);
+    const double* Jp = Jbuf + E.e_jp[e];
+    const double* C = Cq + 6 * (int64_t)E.e_point[e];
+    double M[9];  // Jp * C (C upper triangular)
 #pragma unroll
-  for (int r = 0; r < 3; ++r) {
-    M[r * 3] = Jp[r * 3] * C[0];
-    M[r * 3 + 1] = Jp[r * 3] * C[1] + Jp[r * 3 + 1] * C[3];
-    M[r * 3 + 2] = Jp[r * 3] * C[2] + Jp[r * 3 + 1] * C[4] + Jp[r * 3 + 2] * C[5];
-  }
-  double* z = Z + 18 * e;
-  double* zp = Zp + 18 * (int64_t)E.e_zpos[e];
-#pragma unroll
-  for (int i = 0; i < 6; ++i)
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const double v = Jc[i] * M[k] + Jc[6 + i] * M[3 + k] + Jc[12 + i] * M[6 + k];
-      z[i * 3 + k] = v; zp[i * 3 + k] = v;
+    for (int r = 0; r < 3; ++r) {
+      M[r * 3] = Jp[r * 3] * C[0];
+      M[r * 3 + 1] = Jp[r * 3] * C[1] + Jp[r * 3 + 1] * C[3];
+      M[r * 3 + 2] = Jp[r * 3] * C[2] + Jp[r * 3 + 1] * C[4] + Jp[r * 3 + 2] * C[5];
     }
+    double* z = zs + 19 * threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) z[i * 3 + k] = Jc[i] * M[k] + Jc[6 + i] * M[3 + k] + Jc[12 + i] * M[6 + k];
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 128 * 18; idx += 128) {
+    const int r = idx / 18, c = idx - 18 * r;
+    const int32_t zp = zrow[r];
+    if (zp < 0) continue;
+    const double v = zs[19 * r + c];
+    Z[18 * (e0 + r) + c] = v;
+    Zp[18 * (int64_t)zp + c] = v;
+  }
 }
 
 // ------------------------------------------------------------------------------------------

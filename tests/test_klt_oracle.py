@@ -77,3 +77,46 @@ def test_initial_flow_and_failure_paths(scene):
     bad_init = pts[:2] + np.float32(400.0)
     c4, _, good4, _ = K.track_points(scene["g0"], scene["g1"], pts[:2], init_pts=bad_init)
     assert good4.tolist() == [1, 1] and np.abs(c4 - cur[:2]).max() == 0.0
+
+
+def _rot(axis, deg):
+    a = np.asarray(axis, float) / np.linalg.norm(axis)
+    t = np.deg2rad(deg)
+    Kx = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    return np.eye(3) + np.sin(t) * Kx + (1 - np.cos(t)) * Kx @ Kx
+
+
+def test_predict_keypoints_given_rotation_properties():
+    """predictKeypointsGivenRotation (FeatureTrackerBase.cc:50-105) restated in oracle/klt_oracle.py - properties the reference's arithmetic must
+    have: the identity and any rotation whose quaternion w is within 1e-4 of 1 copy the points; a rotation about the optical axis turns the points
+    about the principal point; two rotations compose; a point that would leave the (shrunken) image or fall behind the camera keeps its place."""
+    from oracle import klt_oracle as KO
+    K = np.array([[500.0, 0, 320.0], [0, 500.0, 240.0], [0, 0, 1.0]])
+    rng = np.random.default_rng(5)
+    pts = np.stack([rng.uniform(60, 580, 200), rng.uniform(60, 420, 200)], 1).astype(np.float32)
+    W, H = 640, 480
+    assert np.array_equal(KO.predict_keypoints_given_rotation(pts, np.eye(3), K, W, H), pts)
+    assert np.array_equal(KO.predict_keypoints_given_rotation(pts, _rot([0, 1, 0], 1.0), K, W, H), pts)      # |1 - |w|| = 3.8e-5 < 1e-4: copied
+    # about the optical axis: x' - c = R2d (x - c)
+    Rz = _rot([0, 0, 1], 8.0)
+    out = KO.predict_keypoints_given_rotation(pts, Rz, K, W, H)
+    c = np.array([320.0, 240.0])
+    want = (pts - c) @ Rz[:2, :2].T + c
+    inside = (want[:, 0] > 1) & (want[:, 0] < W - 1) & (want[:, 1] > 1) & (want[:, 1] < H - 1)
+    assert inside.sum() > 150 and np.abs(out[inside] - want[inside]).max() < 2e-3
+    assert np.array_equal(out[~inside], pts[~inside])                                                         # would leave the image: kept where it was
+    # composition (both rotations above the copy threshold), away from the border
+    R1, R2 = _rot([0.2, 1, 0.1], 4.0), _rot([1, -0.3, 0.2], 3.0)
+    mid = pts[(np.abs(pts[:, 0] - 320) < 120) & (np.abs(pts[:, 1] - 240) < 90)]
+    a = KO.predict_keypoints_given_rotation(KO.predict_keypoints_given_rotation(mid, R1, K, W, H), R2, K, W, H)
+    b = KO.predict_keypoints_given_rotation(mid, R2 @ R1, K, W, H)
+    assert np.abs(a - b).max() < 5e-3
+    # the shrunken image: a larger margin keeps more points in place
+    out0 = KO.predict_keypoints_given_rotation(pts, _rot([0, 1, 0], 12.0), K, W, H)
+    out1 = KO.predict_keypoints_given_rotation(pts, _rot([0, 1, 0], 12.0), K, W, H, shrink_row=60, shrink_col=120)
+    assert (out1 == pts).all(1).sum() > (out0 == pts).all(1).sum()
+    # behind the camera (a 120 degree turn): nothing moves to a negative depth
+    far = KO.predict_keypoints_given_rotation(pts, _rot([0, 1, 0], 120.0), K, W, H)
+    H3 = KO.rotation_homography(_rot([0, 1, 0], 120.0), K).astype(np.float64)
+    z = H3[2, 0] * pts[:, 0] + H3[2, 1] * pts[:, 1] + H3[2, 2]
+    assert np.array_equal(far[z <= 0], pts[z <= 0])

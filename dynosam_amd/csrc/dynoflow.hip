@@ -356,13 +356,25 @@ struct KltLevels {
   int top;   // highest level used
 };
 
+// Exact 64-bit sum over the wavefront (integer addition: any order gives the same bits).  Four DPP steps inside the VALU (lane ^ 1, lane ^ 2,
+// mirror within 8, mirror within 16) leave every lane with the sum of its row of 16, the four rows are read with v_readlane: no trip through the
+// LDS crossbar (six dependent ds_bpermute pairs per sum, two sums per Newton iteration of k_klt, were most of an iteration's latency).
+template <int CTRL>
+__device__ __forceinline__ long long dpp_i64(long long v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(v & 0xFFFFFFFFll), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(v >> 32), CTRL, 0xF, 0xF, true);
+  return ((long long)hi << 32) | (unsigned int)lo;
+}
+__device__ __forceinline__ long long readlane_i64(long long v, int lane) {
+  const int lo = __builtin_amdgcn_readlane((int)(v & 0xFFFFFFFFll), lane), hi = __builtin_amdgcn_readlane((int)(v >> 32), lane);
+  return ((long long)hi << 32) | (unsigned int)lo;
+}
 __device__ __forceinline__ long long wave_sum_i64(long long v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    const int lo = __shfl_xor((int)(v & 0xFFFFFFFFll), off, 64), hi = __shfl_xor((int)(v >> 32), off, 64);
-    v += ((long long)hi << 32) | (unsigned int)lo;
-  }
-  return v;
+  v += dpp_i64<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_i64<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_i64<0x141>(v);   // row_half_mirror
+  v += dpp_i64<0x140>(v);   // row_mirror
+  return (readlane_i64(v, 0) + readlane_i64(v, 16)) + (readlane_i64(v, 32) + readlane_i64(v, 48));
 }
 // exact window sum (|v| < 2^53) -> fp32 with ONE rounding: i64 -> f64 is exact, f64 -> f32 rounds to nearest even
 __device__ __forceinline__ float klt_i64_to_f32(long long v) { return __double2float_rn((double)v); }
@@ -372,6 +384,13 @@ __device__ __forceinline__ void klt_weights(float fx, float fy, int ix, int iy, 
   w4[1] = (int)rintf(kmul(kmul(a, ksub(1.f, b)), sc));
   w4[2] = (int)rintf(kmul(kmul(ksub(1.f, a), b), sc));
   w4[3] = (1 << KLT_W_BITS) - w4[0] - w4[1] - w4[2];
+}
+// the same tap for a window that lies inside the image (x, x + 1 in [0, w), y, y + 1 in [0, h)): no border reflection to compute - the four
+// reflect101 calls were half the integer work of a Newton iteration of k_klt, and nearly every window is inside
+__device__ __forceinline__ int klt_tap_u8_in(const uint8_t* __restrict__ img, int w, int x, int y, const int* w4) {
+  const uint8_t* r0 = img + (size_t)y * w + x;
+  const int v = r0[0] * w4[0] + r0[1] * w4[1] + r0[w] * w4[2] + r0[w + 1] * w4[3];
+  return (v + (1 << (KLT_W_BITS - 5 - 1))) >> (KLT_W_BITS - 5);
 }
 __device__ __forceinline__ int klt_tap_u8(const uint8_t* __restrict__ img, int w, int h, int x, int y, const int* w4) {
   const int x0 = reflect101(x, w), x1 = reflect101(x + 1, w);
@@ -475,12 +494,24 @@ __global__ __launch_bounds__(256) void k_klt(KltLevels L, int n, const float2* _
       int wj[4];
       klt_weights(nx, ny, jx, jy, wj);
       long long t1 = 0, t2 = 0;
+      const bool inside = jx >= 0 && jy >= 0 && jx + KLT_WIN + 1 <= w && jy + KLT_WIN + 1 <= h;   // (the same for every lane)
+      if (inside) {
 #pragma unroll
-      for (int k = 0; k < KLT_PER_LANE; ++k) {
-        const int p = lane + 64 * k;
-        if (p < KLT_NPX) {
-          const int diff = klt_tap_u8(J, w, h, jx + p % KLT_WIN, jy + p / KLT_WIN, wj) - Iw[k];
-          t1 += (long long)diff * Ixw[k]; t2 += (long long)diff * Iyw[k];
+        for (int k = 0; k < KLT_PER_LANE; ++k) {
+          const int p = lane + 64 * k;
+          if (p < KLT_NPX) {
+            const int diff = klt_tap_u8_in(J, w, jx + p % KLT_WIN, jy + p / KLT_WIN, wj) - Iw[k];
+            t1 += (long long)diff * Ixw[k]; t2 += (long long)diff * Iyw[k];
+          }
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < KLT_PER_LANE; ++k) {
+          const int p = lane + 64 * k;
+          if (p < KLT_NPX) {
+            const int diff = klt_tap_u8(J, w, h, jx + p % KLT_WIN, jy + p / KLT_WIN, wj) - Iw[k];
+            t1 += (long long)diff * Ixw[k]; t2 += (long long)diff * Iyw[k];
+          }
         }
       }
       const float b1 = kmul(klt_i64_to_f32(wave_sum_i64(t1)), FLT_SCALE), b2 = kmul(klt_i64_to_f32(wave_sum_i64(t2)), FLT_SCALE);

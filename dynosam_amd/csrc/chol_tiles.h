@@ -1303,10 +1303,7 @@ __global__ __launch_bounds__(CT_BG_THREADS) void k_back_group(BackGroupArgs a, i
 #pragma unroll
       for (int u = 0; u < 8; ++u) acc += mv[u].x * xv[u].x + mv[u].y * xv[u].y;
     }
-    acc += __shfl_xor(acc, 1, 64);
-    acc += __shfl_xor(acc, 2, 64);
-    acc += __shfl_xor(acc, 4, 64);
-    acc += __shfl_xor(acc, 8, 64);
+    acc = row16_sum(acc);
     if (rg == 0) a.S[t.j * CT_TS + c] += acc;
     return;
   }
@@ -1392,8 +1389,7 @@ __global__ __launch_bounds__(CT_BG_THREADS) void k_back_group(BackGroupArgs a, i
         for (int e = 0; e < 4; ++e) mv[e] = mp[e];
         acc += ct_dot8(mv, reinterpret_cast<const double2*>(&xl[sc.i][8 * rg]));
       }
-      acc += __shfl_xor(acc, 1, 64);
-      acc += __shfl_xor(acc, 2, 64);
+      acc = quad_sum(acc);
       const double x = base - acc;
       if (rg == 0) { xl[team][c] = x; a.X[j * CT_TS + c] = x; }
     }

@@ -13,6 +13,19 @@ struct Pose {
   double t[3];
 };
 
+// x of another lane of the same quad / row through DPP (inside the VALU; __shfl_xor goes through the LDS crossbar: two ds_bpermute per double).
+// CTRL: 0xB1 quad_perm [1,0,3,2] = lane ^ 1, 0x4E quad_perm [2,3,0,1] = lane ^ 2, 0x141 row_half_mirror, 0x140 row_mirror.
+// quad_sum / row16_sum give every lane the sum of its quad / row of 16 with the additions of the xor butterfly (1, 2, 4, 8): the same bits.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x) {
+  const long long b = __double_as_longlong(x);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xFFFFFFFFll), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, true);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double quad_sum(double x) { x += dpp_f64<0xB1>(x); x += dpp_f64<0x4E>(x); return x; }
+__device__ __forceinline__ double row16_sum(double x) { x = quad_sum(x); x += dpp_f64<0x141>(x); x += dpp_f64<0x140>(x); return x; }
+
 // c ? a : b component by component (v_cndmask: no divergence, no indexed array)
 __device__ __forceinline__ Pose select_pose(bool c, const Pose& a, const Pose& b) {
   Pose T;

@@ -764,12 +764,9 @@ __global__ void k_point(PointView P, const double* const* __restrict__ Jpp, cons
       g0 += a0 * br; g1 += a1 * br; g2 += a2 * br;
     }
   }
-#pragma unroll
-  for (int m = 1; m < 4; m <<= 1) {   // (the lanes of a quad are adjacent and took the same branches)
-    h00 += __shfl_xor(h00, m, 64); h01 += __shfl_xor(h01, m, 64); h02 += __shfl_xor(h02, m, 64);
-    h11 += __shfl_xor(h11, m, 64); h12 += __shfl_xor(h12, m, 64); h22 += __shfl_xor(h22, m, 64);
-    g0 += __shfl_xor(g0, m, 64); g1 += __shfl_xor(g1, m, 64); g2 += __shfl_xor(g2, m, 64);
-  }
+  // (the lanes of a quad are adjacent and took the same branches)
+  h00 = quad_sum(h00); h01 = quad_sum(h01); h02 = quad_sum(h02); h11 = quad_sum(h11); h12 = quad_sum(h12); h22 = quad_sum(h22);
+  g0 = quad_sum(g0); g1 = quad_sum(g1); g2 = quad_sum(g2);
   if (jl) return;
   if (ddamp) { h00 += lm_damp(lambda, true, h00); h11 += lm_damp(lambda, true, h11); h22 += lm_damp(lambda, true, h22); }
   // Cholesky H = L L^T
@@ -1652,8 +1649,7 @@ __global__ void k_backsub_points(PointEdgeView V, const double* __restrict__ Z, 
     for (int i = 0; i < 6; ++i) { s0 -= z[i * 3] * d[i]; s1 -= z[i * 3 + 1] * d[i]; s2 -= z[i * 3 + 2] * d[i]; }
   }
   // (lanes of a quad are adjacent and take the same branches: the whole quad is here)
-  s0 += __shfl_xor(s0, 1, 64); s1 += __shfl_xor(s1, 1, 64); s2 += __shfl_xor(s2, 1, 64);
-  s0 += __shfl_xor(s0, 2, 64); s1 += __shfl_xor(s1, 2, 64); s2 += __shfl_xor(s2, 2, 64);
+  s0 = quad_sum(s0); s1 = quad_sum(s1); s2 = quad_sum(s2);
   if (j) return;
   if (V.chained && V.chained[q] == 1) {   // k_chain_backsub finishes along the chain
     dpoint[3 * q] = s0; dpoint[3 * q + 1] = s1; dpoint[3 * q + 2] = s2;

@@ -70,7 +70,8 @@ class ParallelObjectSmoothers:
         for j in sorted(set(int(o) for o in dy[:, 1])):
             if j not in self.estimators:
                 self.estimators[j] = DecoupledObjectFormulation(j, self.p, pose_sigmas or (0.01, 0.01, 0.01, 0.1, 0.1, 0.1))
-            sub = FramePacket(pk.frame_id, X, None, np.zeros((0, 4)), dy[dy[:, 1] == j], {j: pk.motions[j]} if j in pk.motions else {})
+            sub = FramePacket(pk.frame_id, X, None, np.zeros((0, 4)), dy[dy[:, 1] == j], {j: pk.motions[j]} if j in pk.motions else {},
+                              dynamic_cov=None if getattr(pk, "dynamic_cov", None) is None else np.asarray(pk.dynamic_cov, float).reshape(-1, 9)[dy[:, 1] == j])
             if pose_sigmas is not None:
                 sub.pose_sigmas = list(pose_sigmas)     # this frame's sensor-pose prior: the covariance the static estimator reports (:493-503)
             self.estimators[j].update(sub)

@@ -71,9 +71,10 @@ def make_pair(width=640, height=480, objects=3, seed=4, max_flow=8.0):
     return dict(rgb0=rgb0, rgb1=rgb1, mask0=mask0, mask1=mask1, flow_gt=flow.astype(np.float32), valid=valid, u_bg=u_bg)
 
 
-def make_sequence(width=640, height=480, objects=3, frames=10, seed=4, max_flow=6.0):
+def make_sequence(width=640, height=480, objects=3, frames=10, seed=4, max_flow=6.0, return_flow=False):
     """a short stream for the composed tracker: the static scene slides by an integer flow per frame, every object moves rigidly
-    (constant translation + small rotation / scale per frame about its own moving centre).  returns (rgb [F,H,W,3] u8, mask [F,H,W] i32)."""
+    (constant translation + small rotation / scale per frame about its own moving centre).  returns (rgb [F,H,W,3] u8, mask [F,H,W] i32);
+    with return_flow also the exact flow images [F,H,W,2] f32 (frame f -> f+1: what ImageContainer::opticalFlow() of frame f holds)."""
     rng = np.random.default_rng(seed)
     ys, xs = np.mgrid[0:height, 0:width].astype(np.float64)
     bg = _texture(rng)
@@ -97,4 +98,22 @@ def make_sequence(width=640, height=480, objects=3, frames=10, seed=4, max_flow=
             img = np.where(inside[..., None], o["tex"](ox, oy), img)
             mask = np.where(inside, j + 1, mask)
         rgbs.append(np.clip(np.round(127.5 + 105.0 * img), 0, 255).astype(np.uint8)); masks.append(mask)
-    return np.stack(rgbs), np.stack(masks)
+    if not return_flow:
+        return np.stack(rgbs), np.stack(masks)
+    flows = []
+    for f in range(frames):
+        fl = np.zeros((height, width, 2))
+        fl[..., 0], fl[..., 1] = u_bg[0], u_bg[1]
+        for j, o in enumerate(objs):
+            th, sc = f * o["th"], o["sc"] ** f
+            Mi = np.linalg.inv(sc * np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]]))
+            th1, sc1 = (f + 1) * o["th"], o["sc"] ** (f + 1)
+            M1 = sc1 * np.array([[np.cos(th1), -np.sin(th1)], [np.sin(th1), np.cos(th1)]])
+            A = M1 @ Mi                                              # x' = c_{f+1} + A (x - c_f)
+            cf, cf1 = o["c"] + f * o["t"], o["c"] + (f + 1) * o["t"]
+            dx, dy = xs - cf[0], ys - cf[1]
+            sel = masks[f] == j + 1
+            fl[..., 0] = np.where(sel, cf1[0] + A[0, 0] * dx + A[0, 1] * dy - xs, fl[..., 0])
+            fl[..., 1] = np.where(sel, cf1[1] + A[1, 0] * dx + A[1, 1] * dy - ys, fl[..., 1])
+        flows.append(fl.astype(np.float32))
+    return np.stack(rgbs), np.stack(masks), np.stack(flows)

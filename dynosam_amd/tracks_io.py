@@ -157,4 +157,6 @@ def to_frame_packet(p: TrackPacket):
     from .formulation import FramePacket
     return FramePacket(int(p.frame_id), np.asarray(p.X_world), None if p.T_k_1_k is None else np.asarray(p.T_k_1_k),
                        np.asarray(p.static)[:, [0, 3, 4, 5]] if len(p.static) else np.zeros((0, 4)),
-                       np.asarray(p.dynamic)[:, [0, 1, 4, 5, 6]] if len(p.dynamic) else np.zeros((0, 5)), dict(p.motions))
+                       np.asarray(p.dynamic)[:, [0, 1, 4, 5, 6]] if len(p.dynamic) else np.zeros((0, 5)), dict(p.motions),
+                       static_cov=None if p.static_cov is None else np.asarray(p.static_cov, float).reshape(-1, 9),
+                       dynamic_cov=None if p.dynamic_cov is None else np.asarray(p.dynamic_cov, float).reshape(-1, 9))

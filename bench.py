@@ -48,6 +48,10 @@ def main():
                     help="library (default): RCCL inside libdynogfx (ncclAllReduce enqueued on the solver's streams, no host round trip); "
                          "torch: the blocking all-reduce callback through torch.distributed")
     ap.add_argument("--scale", type=int, default=0, help="trajectory multiplier of the weak-scaling graph (default: world size)")
+    ap.add_argument("--no-track-cut", action="store_true",
+                    help="weak-scaling graph (N > 1): let feature tracks run across the borders of the ranks' keyframe windows (separators as wide as the "
+                         "longest track: 13 frames).  Default: the frontend ends tracks at the window borders, as max_feature_track_age ends every track "
+                         "(TrackerParams.hpp) - same landmarks / observations / factors, separators 2 frames wide (odometry + motion smoothing)")
     args = ap.parse_args()
 
     import numpy as np
@@ -86,7 +90,8 @@ def main():
         g1 = synth.make_hybrid_graph(cfg)
         base_factors = g1.n_factors
         cfg = synth.config(args.config, frames=cfg.frames * mult, static_points=cfg.static_points * mult,
-                           dynamic_points_per_object=cfg.dynamic_points_per_object * mult)
+                           dynamic_points_per_object=cfg.dynamic_points_per_object * mult,
+                           cut_tracks_every=0 if args.no_track_cut else cfg.frames)
     g = synth.make_hybrid_graph(cfg)
     if base_factors is None:
         base_factors = g.n_factors
@@ -241,6 +246,7 @@ def main():
                                    f"{g.n_factors} factors, {g.n_vars} variables, Huber k=1e-4, GTSAM-default LM",
                        "factors": g.n_factors, "variables": g.n_vars, "inner_iterations": int(rep.inner_iterations),
                        "error_before": rep.error_before, "error_after": rep.error_after, "sharding": f"keyframe-window x{world}",
+                       "track_cut_frames": int(cfg.cut_tracks_every), "schedule": ctx.schedule(),
                        "collective": collective_kind,
                        "lambda_search": {"solves_queued": int(rep.solves_queued), "solves_used": int(rep.solves_used),
                                          "speculative_queued": int(rep.spec_queued), "speculative_used": int(rep.spec_used)},

@@ -274,7 +274,9 @@ struct TileSym {
     struct Item { FwdSrc s; int32_t next; };
     std::vector<Item> items;
     // split tasks (split_max): scratch tiles are handed out per launch and come back two launches later (used in launch L, added and cleared in L + 1)
-    const int split = (n_elim < 0 && !want_df) ? split_max : 0;
+    // (sharded schedules, two_phase: a scratch tile handed out in launch L is added and cleared in L + 1 of the SAME phase - the deadline rule
+    //  below never splits in a phase's last launch - so every scratch tile is zero again where the phases meet, i.e. at the all-reduce)
+    const int split = (!want_df && (n_elim < 0 || two_phase)) ? split_max : 0;
     struct Due { int32_t tgt, scratch, col; bool diag; };
     std::vector<Due> due, due_next;
     std::vector<int32_t> free_ids, add_a((size_t)(split > 0 ? n_tiles : 0), 0), add_b(add_a);

@@ -115,6 +115,11 @@ int main(int argc, char** argv) {
   std::vector<double> P(TT), Q(TT), tmp(TS);
   // ---- forward ----
   for (size_t l = 0; l + 1 < sym.flaunch.size(); ++l) {
+    // where the phases of a sharded schedule meet (the all-reduce over [tiles | scratch tiles | rhs]) every scratch tile must be zero again
+    if (sym.phase_end.size() > 1 && (int32_t)l == sym.phase_end[0]) {
+      for (size_t e = (size_t)sym.n_tiles * TT; e < A.size(); ++e) if (A[e] != 0.0) { printf("FAIL: a scratch tile is not zero where the phases meet\n"); return 1; }
+      for (size_t e = (size_t)npad; e < r.size(); ++e) if (r[e] != 0.0) { printf("FAIL: a scratch rhs segment is not zero where the phases meet\n"); return 1; }
+    }
     std::vector<int32_t> ids;
     for (int32_t t = sym.flaunch[l]; t < sym.flaunch[l + 1]; ++t) ids.push_back(t);
     std::shuffle(ids.begin(), ids.end(), rng);

@@ -155,6 +155,10 @@ class ScenarioConfig:
     smoothing_sigma_trans: float = 0.1
     prior_sigma: float = 1e-6          # BackendDefinitions.cc:137-138
     noise_scale: float = 1.0           # 0 → noiseless measurements and ground-truth init
+    cut_tracks_every: int = 0          # > 0: no feature track crosses a multiple of this many frames - the frontend ends tracks at the borders of the
+                                       # keyframe windows the graph is sharded by, the way TrackerParams::max_feature_track_age ends every track after
+                                       # 25 frames (dynosam/include/dynosam/frontend/vision/TrackerParams.hpp).  A track that would cross a border is
+                                       # moved to the side most of it lies on: same number of landmarks, observations and factors.
 
 
 def config(n: int, **kw) -> ScenarioConfig:
@@ -174,6 +178,25 @@ def _perturb(rng, pose, s_rot, s_trans):
     n = pose[1].shape[0]
     xi = np.concatenate([rng.normal(0, 1, (n, 3)) * s_rot, rng.normal(0, 1, (n, 3)) * s_trans], -1)
     return compose(pose, se3_exp(xi))
+
+
+def _keep_tracks_inside_windows(birth, length, every, lo=None, hi=None):
+    """cut_tracks_every: births moved so that [birth, birth + length) crosses no multiple of `every`; lo / hi (per track): the frames the
+    track may occupy (an object's lifetime) - a track that cannot be moved inside them is shortened at the border instead"""
+    birth, length = birth.copy(), length.copy()
+    if every <= 0 or not len(birth):
+        return birth, length
+    lo = np.zeros_like(birth) if lo is None else lo
+    hi = np.full_like(birth, np.iinfo(birth.dtype).max) if hi is None else hi
+    border = (birth // every + 1) * every                      # first border behind the birth frame
+    cross = border < birth + length
+    before = border - birth                                    # observations in front of the border
+    to_front = cross & (2 * before >= length) & (border - length >= lo) & (border - length >= (border - every))
+    to_back = cross & ~to_front & (border + length <= hi)
+    rest = cross & ~to_front & ~to_back
+    birth = np.where(to_front, border - length, np.where(to_back, border, birth))
+    length = np.where(rest, np.maximum(before, 1), length)     # (cannot move: the track ends at the border)
+    return birth, length
 
 
 def make_hybrid_graph(cfg: ScenarioConfig) -> FlatGraph:
@@ -249,6 +272,7 @@ def make_hybrid_graph(cfg: ScenarioConfig) -> FlatGraph:
     s_len = rng.integers(cfg.static_track[0], cfg.static_track[1] + 1, Ns)
     s_birth = rng.integers(0, max(1, K - cfg.static_track[0] + 1), Ns)
     s_len = np.minimum(s_len, K - s_birth)
+    s_birth, s_len = _keep_tracks_inside_windows(s_birth, s_len, cfg.cut_tracks_every, hi=np.full_like(s_birth, K))
     # sampled in the frustum of the camera at the track's mid frame so it stays in view
     depth = rng.uniform(2.0, 45.0, Ns)
     uv = np.stack([rng.uniform(-0.55, 0.55, Ns), rng.uniform(-0.4, 0.4, Ns)], -1)
@@ -272,6 +296,7 @@ def make_hybrid_graph(cfg: ScenarioConfig) -> FlatGraph:
     span = (obj_end - obj_start)[d_obj]
     d_birth = obj_start[d_obj] + (rng.uniform(0, 1, Nd) * np.maximum(1, span - cfg.dynamic_track[0] + 1)).astype(int)
     d_len = np.minimum(d_len, obj_end[d_obj] - d_birth)
+    d_birth, d_len = _keep_tracks_inside_windows(d_birth, d_len, cfg.cut_tracks_every, lo=obj_start[d_obj], hi=obj_end[d_obj])
     m_obj_gt = rng.normal(0, 0.5, (Nd, 3))  # in the (ground-truth) object frame
     do_track = np.repeat(np.arange(Nd), d_len)
     do_frame = np.concatenate([np.arange(b, b + n) for b, n in zip(d_birth, d_len)]) if Nd else np.zeros(0, int)

@@ -318,3 +318,49 @@ def test_sharded_marginalisation_matches_the_single_context(world):
             assert prior.Lambda is None and prior.eta is None
     assert n_cont == n_cont0                       # every untouched factor became a container on exactly one rank
     c.close()
+
+
+def cut_graph(world, frames_per_rank=40, cut=True):
+    frames = frames_per_rank * world
+    return synth.make_hybrid_graph(synth.config(5, frames=frames, objects=max(2, world), static_points=20 * frames, dynamic_points_per_object=160, object_lifetime=2 * frames_per_rank,
+                                                seed=5, cut_tracks_every=frames_per_rank if cut else 0))
+
+
+@pytest.mark.parametrize("cut", [True, False])
+def test_eight_ranks_follow_the_single_context_and_tracks_cut_at_the_window_borders_narrow_the_separators(cut):
+    """world = 8 (the node BASELINE names): LM on eight in-process ranks == the single-context solve of the same graph - identical accept /
+    reject trace and counts, final cost 1e-6, replicas bit-identical.  With the feature tracks ended at the borders of the keyframe windows
+    (synth.ScenarioConfig.cut_tracks_every, the way max_feature_track_age ends tracks) only the odometry and the motion smoothing couple two
+    windows: every separator is 2 frames wide instead of the longest track (13), phase B of the factorisation - the launches behind the
+    all-reduce, run redundantly by every rank - shrinks accordingly; the schedule is the same on every rank."""
+    from dynosam_amd.optimizer import Context, LevenbergMarquardtParams
+    world = 8
+    g = cut_graph(world, cut=cut)
+    P = LevenbergMarquardtParams()
+    P.max_iterations = 6
+    c = Context(); c.upload(g)
+    r0 = c.optimize(P)
+    v0 = c.values()
+    one = c.schedule()
+    c.close()
+
+    def work(ctx):
+        r = ctx.optimize(P)
+        return r, ctx.values(), ctx.schedule()
+
+    res = run_ranks(g, world, work)
+    for r, v, _s in res:
+        assert r.iterations == r0.iterations and r.inner_iterations == r0.inner_iterations
+        assert [r.trace_accepted[i] for i in range(r.trace_len)] == [r0.trace_accepted[i] for i in range(r0.trace_len)]
+        assert abs(r.error_after - r0.error_after) <= 1e-6 * r0.error_after
+        assert np.abs(v - v0).max() <= 1e-5
+    for _r, v, _s in res[1:]:
+        assert np.array_equal(v, res[0][1])
+    sch = [s for _r, _v, s in res]
+    assert len({(s["sep_frames_max"], s["sep_frames_min"], s["scratch_tiles"], s["forward_launches"] - s["phase_a_launches"]) for s in sch}) == 1
+    phase_b = sch[0]["forward_launches"] - sch[0]["phase_a_launches"]
+    if cut:
+        assert sch[0]["sep_frames_max"] == 2 and phase_b <= 10
+    else:
+        assert sch[0]["sep_frames_max"] >= 10 and phase_b >= 20
+    assert one["sep_frames_max"] == 0

@@ -105,3 +105,54 @@ def test_invalid_graphs_return_the_documented_status(shim):
         print("ok")
         """)
     assert "ok" in out
+
+
+def test_sharded_schedule_at_eight_ranks(shim):
+    """The symbolic side of the sharded path at north_star's node size, without a GPU: eight in-process ranks (threads; the SUM callback adds
+    the ranks' host buffers) upload their shards of a 320-frame graph.  With feature tracks ended at the window borders every separator is
+    2 frames (odometry + motion smoothing are all that crosses a border) and phase B - the launches behind the all-reduce, which every rank
+    runs redundantly - is a fraction of what it is when the separators must be as wide as the longest track; phase A is one window's own
+    elimination either way; every rank reserves the same number of scratch tiles (they lie inside the all-reduced range)."""
+    out, _ = run_child(shim, """
+        import threading, ctypes as C, numpy as np
+        from dynosam_amd import synth
+        from dynosam_amd.optimizer import Context
+        N = 8
+        def schedule(cut):
+            frames = 40 * N
+            g = synth.make_hybrid_graph(synth.config(5, frames=frames, objects=N, static_points=20 * frames, dynamic_points_per_object=160, object_lifetime=80, seed=5,
+                                                    cut_tracks_every=40 if cut else 0))
+            bar = threading.Barrier(N); slots = [None] * N; out = [None] * N; err = []
+            def cb(rank):
+                def fn(ptr, count):
+                    a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_double)), (count,))
+                    slots[rank] = a.copy(); bar.wait()
+                    tot = slots[0].copy()
+                    for r in range(1, N):
+                        tot += slots[r]
+                    a[:] = tot; bar.wait()
+                return fn
+            def body(r):
+                try:
+                    c = Context(world_size=N, rank=r, allreduce=cb(r))
+                    c.upload(g.shard(r, N))
+                    out[r] = c.schedule(); c.close()
+                except BaseException as e:
+                    err.append(e); bar.abort()
+            th = [threading.Thread(target=body, args=(r,)) for r in range(N)]
+            [t.start() for t in th]; [t.join() for t in th]
+            if err:
+                raise err[0]
+            return out
+        cut, full = schedule(True), schedule(False)
+        for s in (cut, full):
+            assert len({(x["sep_frames_max"], x["sep_frames_min"], x["scratch_tiles"]) for x in s}) == 1, s
+        b_cut = max(x["forward_launches"] - x["phase_a_launches"] for x in cut)
+        b_full = min(x["forward_launches"] - x["phase_a_launches"] for x in full)
+        assert cut[0]["sep_frames_max"] == cut[0]["sep_frames_min"] == 2, cut[0]
+        assert full[0]["sep_frames_max"] >= 12, full[0]
+        assert b_cut <= 10 and b_full >= 2 * b_cut, (b_cut, b_full)
+        assert max(x["tile_columns"] - x["phase_a_columns"] for x in cut) * 3 <= min(x["tile_columns"] - x["phase_a_columns"] for x in full)
+        print("ok", b_cut, b_full)
+        """)
+    assert "ok" in out

@@ -98,3 +98,22 @@ def test_split_tasks_solve_the_system(checker):
         assert res[0]["scratch"] == 0
         if res[0]["max_src"] >= 2:
             assert res[1]["scratch"] > 0 and res[1]["fwd_tasks"] > res[0]["fwd_tasks"] and res[1]["max_src"] < res[0]["max_src"]
+
+
+def test_split_tasks_in_a_two_phase_schedule_leave_no_scratch_at_the_phase_boundary(checker):
+    """the sharded path (round 5: split tasks are on there too): phase A = the rank's interior, the all-reduce over [tiles | scratch | rhs],
+    phase B = the separators.  A scratch tile handed out in one launch is added and cleared in the next launch of the SAME phase, never across
+    the boundary - the checker fails if anything is left in a scratch tile or scratch rhs segment where the phases meet, or at the end"""
+    used = 0
+    for args, nel in (((660, 3, 2, 5, 0, 10), 40), ((1320, 2, 2, 9, 30, 10), 60), ((1200, 84, 1, 7, 0, 560), 150), ((660, 3, 2, 2, 20, 10), 55)):
+        res = {}
+        for sp in (0, 1, 2):
+            out = subprocess.run([checker, *map(str, args)], capture_output=True, text=True, timeout=300,
+                                 env=dict(os.environ, TS_SPLIT=str(sp), TS_ROW_MIN="0", TS_NELIM=str(nel)))
+            assert out.returncode == 0, out.stdout + out.stderr
+            res[sp] = {k: float(v) for k, v in (tok.split("=") for tok in out.stdout.split() if "=" in tok)}
+            assert res[sp]["residual"] < 1e-10 and res[sp]["phases"] == 2
+            assert res[sp]["fwd_launches"] == res[0]["fwd_launches"]
+        assert res[0]["scratch"] == 0
+        used += int(res[1]["scratch"] > 0)
+    assert used >= 2

@@ -100,6 +100,7 @@ class HybridFormulation:
         # ---- map (MapNodes.hpp): everything iterates in id order ----
         self.frames = []                          # frame ids in arrival order
         self.X_init = {}                          # frame -> pose
+        self.X_sig = {}                           # frame -> sigmas its sensor pose measurement came with (decoupled object estimators)
         self.static_meas = {}                     # tracklet -> {frame: z}
         self.dyn_meas = {}                        # tracklet -> {frame: z}
         self.static_R = {}                        # tracklet -> {frame: sqrt information [9] of the measurement's own model} (absent: the params' sigma)
@@ -210,6 +211,10 @@ class HybridFormulation:
         dy = np.asarray(pk.dynamic, float).reshape(-1, 5)
         fs = set(self.frame_static.get(k, []))
         self.frame_objects.setdefault(k, [])
+        if pk.X_world is not None:                                   # Map::updateSensorPoseMeasurement (Map.hpp:130-145): overwrites
+            self.X_init[k] = from12(np.asarray(pk.X_world, float))
+            if getattr(pk, "pose_sigmas", None) is not None:
+                self.X_sig[k] = [float(x) for x in pk.pose_sigmas]
         for i, row in enumerate(st):
             t = int(row[0])
             assert t not in self.dyn_meas, "tracklet is already a landmark of an object (Map.hpp:451 CHECK_EQ object_id)"

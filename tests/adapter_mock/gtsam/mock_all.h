@@ -71,6 +71,7 @@ class Values {
   template <class T> const T& at(Key k) const { return dynamic_cast<const GenericValue<T>&>(*m.at(k)).value(); }
   KeyVector keys() const { KeyVector k; for (auto& e : m) k.push_back(e.first); return k; }
   size_t size() const { return m.size(); }
+  bool exists(Key k) const { return m.count(k) != 0; }
  private:
   std::map<Key, std::shared_ptr<Value>> m;
 };

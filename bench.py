@@ -289,7 +289,7 @@ def main():
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/r02_pmc_hbm.txt: separate
     FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); None if absent."""
-    for name in ("r04_pmc_hbm.txt", "r03_pmc_hbm.txt", "r02_pmc_hbm.txt", "r01_pmc_hbm.txt"):
+    for name in ("r05_pmc_hbm.txt", "r04_pmc_hbm.txt", "r03_pmc_hbm.txt", "r02_pmc_hbm.txt", "r01_pmc_hbm.txt"):
         try:
             for ln in open(os.path.join(ROOT, "profiles", name)):
                 t = ln.split()

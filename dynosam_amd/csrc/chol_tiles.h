@@ -173,6 +173,62 @@ __device__ __forceinline__ ct_d4 ct_mma_ra_bt(const double (&pa)[8], const doubl
   }
   return acc + odd;
 }
+// P' = X T^-1 for the wave's tile-row block bi, straight into the A-operand registers of the NEXT contraction (round 5).  The strip is formed
+// TRANSPOSED, D_bk = T^-1(16 bk .., :) X(16 bi .., :)^T for bk = 0, 1: result register r of lane (lc, lr) of D_bk is
+// P'[16 bi + lc][16 bk + lr + 4 r] - and lane (lc, lr) supplies exactly A[16 bi + lc][lr + 4 kk] for k-chunk kk of ct_mma_ra_bt, so
+// pa[4 bk + r] = (-) D_bk[r] with no cross-lane traffic, no LDS round trip and no barrier between the two contractions of an update.  Both waves
+// of a block row form the same strip (16 MFMAs instead of 8 per wave: the matrix pipe was 23 % busy); the four accumulation chains are
+// independent, so the strip costs the latency of one block (tile_sym / ubench: a dependent v_mfma_f64_16x16x4 issues every ~128 cycles, an
+// independent one every ~33).  Every element is the same sum of the same products in the same order as ct_mma_abt<false>(X, LI) gave:
+// bit-identical P'.
+#ifndef CT_PSTRIP
+#define CT_PSTRIP 0            // 0 (default): P' goes through LDS between the two contractions of an update; 1 / 2: the register forms below -
+#endif                         // built and measured in round 5, both slower (profiles/r05_ab_misc.txt): kept for the A/B only
+#ifndef CT_PSTRIP_UNROLL
+#define CT_PSTRIP_UNROLL 4     // k-chunk pairs of the strip's loop in flight (4 = all; fewer = fewer operand registers)
+#endif
+template <bool NEG>
+__device__ __forceinline__ void ct_pstrip(const double* __restrict__ X, const double* __restrict__ LI, int bi, int lane, double (&pa)[8]) {
+  const int lr = lane >> 4, lc = lane & 15;
+  ct_d4 d0 = {0.0, 0.0, 0.0, 0.0}, e0 = d0, d1 = d0, e1 = d0;
+#pragma unroll CT_PSTRIP_UNROLL
+  for (int kk = 0; kk < 8; kk += 2) {
+    const double b = X[ct_ix(16 * bi + lc, lr + 4 * kk)], b1 = X[ct_ix(16 * bi + lc, lr + 4 * (kk + 1))];
+    const double t0 = LI[ct_ix(lc, lr + 4 * kk)], t1 = LI[ct_ix(16 + lc, lr + 4 * kk)];
+    const double u0 = LI[ct_ix(lc, lr + 4 * (kk + 1))], u1 = LI[ct_ix(16 + lc, lr + 4 * (kk + 1))];
+    d0 = __builtin_amdgcn_mfma_f64_16x16x4f64(t0, b, d0, 0, 0, 0);
+    d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(t1, b, d1, 0, 0, 0);
+    e0 = __builtin_amdgcn_mfma_f64_16x16x4f64(u0, b1, e0, 0, 0, 0);
+    e1 = __builtin_amdgcn_mfma_f64_16x16x4f64(u1, b1, e1, 0, 0, 0);
+  }
+  d0 += e0; d1 += e1;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { pa[r] = NEG ? -d0[r] : d0[r]; pa[4 + r] = NEG ? -d1[r] : d1[r]; }
+}
+// The k-half `h` of that strip alone (8 MFMAs, two chains): ph[r] = (-) P'[16 bi + lc][16 h + lr + 4 r], the A operand of k-chunks kk = 4 h + r.
+// CT_PSTRIP == 2: wave (bi, bj) forms half bj and multiplies it into PARTIAL accumulators of both output blocks of its tile row; the two
+// waves of a row add their partials once per task instead of handing P' through LDS once per source.
+template <bool NEG>
+__device__ __forceinline__ void ct_phalf(const double* __restrict__ X, const double* __restrict__ LI, int bi, int h, int lane, double (&ph)[4]) {
+  const int lr = lane >> 4, lc = lane & 15;
+  ct_d4 d = {0.0, 0.0, 0.0, 0.0}, e = d;
+#pragma unroll
+  for (int kk = 0; kk < 8; kk += 2) {
+    const double b = X[ct_ix(16 * bi + lc, lr + 4 * kk)], b1 = X[ct_ix(16 * bi + lc, lr + 4 * (kk + 1))];
+    const double t0 = LI[ct_ix(16 * h + lc, lr + 4 * kk)], u0 = LI[ct_ix(16 * h + lc, lr + 4 * (kk + 1))];
+    d = __builtin_amdgcn_mfma_f64_16x16x4f64(t0, b, d, 0, 0, 0);
+    e = __builtin_amdgcn_mfma_f64_16x16x4f64(u0, b1, e, 0, 0, 0);
+  }
+  d += e;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) ph[r] = NEG ? -d[r] : d[r];
+}
+// block (bi, bk) of a strip held as pa (ct_pstrip) to a tile in global memory: element (16 bi + lc, 16 bk + lr + 4 r)
+__device__ __forceinline__ void ct_gstore_strip_block(double* __restrict__ G, int bi, int bk, int lane, const double (&pa)[8], double sign) {
+  const int lr = lane >> 4, lc = lane & 15;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) G[16 * bi + lc + CT_TS * (16 * bk + lr + 4 * r)] = sign * (bk ? pa[4 + r] : pa[r]);
+}
 __device__ __forceinline__ void ct_store_frag(double* __restrict__ T, int bi, int bj, int lane, ct_d4 acc) {
   const int lr = lane >> 4, lc = lane & 15;
 #pragma unroll
@@ -906,7 +962,7 @@ __device__ __forceinline__ void ct_run_task(const CholLevelArgs& a, const FwdTas
   double* const XA = S.XA; double* const XB = S.XB; double* const LI = S.LI;
   // the products P, Q overwrite their own operands (a barrier separates the last operand read from the first product
   // write): three tile buffers instead of five - LDS was what limited the workgroups per CU
-  double* const Pt = XA;
+  (void)XB;
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, bi = w >> 1, bj = w & 1;
   const ct_d4 zero = {0.0, 0.0, 0.0, 0.0};
 #define CT_END_STAMP() do { if (dbg_all) dbg_all[1] = (long long)__builtin_readcyclecounter(); } while (0)
@@ -928,13 +984,20 @@ __device__ __forceinline__ void ct_run_task(const CholLevelArgs& a, const FwdTas
     ct_lst(XB, tid, vb);
     ct_lst(LI, tid, vl);
     __syncthreads();
+#if CT_PSTRIP == 1
+    int cur = t.tgt;
+    double pa[8];
+    ct_pstrip<true>(XA, LI, bi, lane, pa);   // -P' in the A-operand registers (T^-1 is symmetric)
+    __syncthreads();                     // every wave has read T^-1: LI is free from here on
+#else
     const ct_d4 p = ct_mma_abt<false>(XA, LI, bi, bj, lane, zero);   // T^-1 is symmetric
     __syncthreads();
-    ct_store_frag(Pt, bi, bj, lane, p);
+    ct_store_frag(XA, bi, bj, lane, p);
     __syncthreads();                     // P' published; LI is free from here on
     int cur = t.tgt;
     double pa[8];
-    ct_load_neg_afrag(Pt, bi, lane, pa);
+    ct_load_neg_afrag(XA, bi, lane, pa);
+#endif
     for (int i = 0;; ++i) {
       acc = ct_mma_ra_bt(pa, (i & 1) ? LI : XB, bj, lane, acc);
       ct_gstore_frag_x<DF>(a.A + (int64_t)cur * CT_TT, bi, bj, lane, acc);
@@ -985,10 +1048,16 @@ __device__ __forceinline__ void ct_run_task(const CholLevelArgs& a, const FwdTas
   // finalising workgroup of column K only has to leave its final r_K behind (a.Y), not w_K = T_K^-1 r_K
   auto rhs_fold = [&]() {
     if (rhs_own) {
+#if CT_PSTRIP == 1
+      rv -= S.part[0][rt];               // (the product arrives summed over its row, ct_run_task below)
+#elif CT_PSTRIP == 2
+      rv -= S.part[0][rt] + S.part[1][rt];   // (one partial per k-half)
+#else
       double ssum = 0.0;
 #pragma unroll
       for (int g = 0; g < 8; ++g) ssum += S.part[g][rt];
       rv -= ssum;
+#endif
     }
   };
   if (t.nsrc) {
@@ -1003,6 +1072,9 @@ __device__ __forceinline__ void ct_run_task(const CholLevelArgs& a, const FwdTas
     // only the lower triangle is ever read): two contractions per source
     ct_t2 va = ct_gld_x<DF>(a.A + (int64_t)s.ai * CT_TT, tid), vb = ct_gld_x<DF>(a.A + (int64_t)s.aj * CT_TT, tid), vl = ct_gld_x<DF>(a.Tinv + (int64_t)s.k * CT_TT, tid);
     double wv = ct_ld_x<DF>(a.Y + s.k * CT_TS + (tid & 31));
+#if CT_PSTRIP == 2
+    ct_d4 acc2[2] = {bj == 0 ? acc : zero, bj == 1 ? acc : zero};   // partial accumulators of blocks (bi, 0) and (bi, 1): the target rides in its owner's
+#endif
     for (int q = 0; q < ns; ++q) {
       if (q) {
         __syncthreads();                 // previous source fully consumed
@@ -1022,10 +1094,56 @@ __device__ __forceinline__ void ct_run_task(const CholLevelArgs& a, const FwdTas
       s = sn; sn = sn2;
       __syncthreads();
       if (q == 0) CT_STAMP(1);
-      const ct_d4 p = ct_mma_abt<false>(XA, LI, bi, bj, lane, zero);   // T^-1 is stored exactly symmetric
+#if CT_PSTRIP == 2
+      // wave (bi, bj): the k-half bj of -P' = -A(I,K) T_K^-1 in registers, multiplied into the partial accumulators of BOTH blocks of tile row bi
+      double ph[4];
+      ct_phalf<true>(XA, LI, bi, bj, lane, ph);
+      if (diag) {                          // the panel product M(I,K) = P' for the backward substitution: this wave's block (bi, bj)
+        double* const G = a.L + (int64_t)cur_ai * CT_TT;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) G[16 * bi + (lane & 15) + CT_TS * (16 * bj + (lane >> 4) + 4 * r)] = -ph[r];
+      }
+      {
+        const double* const Y = diag ? XA : XB;
+        const int lr = lane >> 4, lc = lane & 15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int kcol = lr + 4 * (4 * bj + r);
+          acc2[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(ph[r], Y[ct_ix(lc, kcol)], acc2[0], 0, 0, 0);
+          acc2[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ph[r], Y[ct_ix(16 + lc, kcol)], acc2[1], 0, 0, 0);
+        }
+        if (diag) {
+          // r_I -= P' r_K over this wave's k-half; the four lanes of a row meet through two bpermutes
+          double ps = 0.0;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ps = fma(-ph[r], S.wk[16 * bj + lr + 4 * r], ps);
+          ps += __shfl_xor(ps, 16, 64);
+          ps += __shfl_xor(ps, 32, 64);
+          if (lr == 0) S.part[bj][16 * bi + lc] = ps;
+        }
+      }
+    }
+#elif CT_PSTRIP == 1
+      double pa[8];
+      ct_pstrip<true>(XA, LI, bi, lane, pa);   // -P' = -A(I,K) T_K^-1 (T^-1 is stored exactly symmetric), already the next contraction's A operand
       // P'(I,K) of a DIAGONAL target is the panel product M(I,K) = A(I,K) T_K^-1 the backward substitution multiplies x_I with
       // (every off-diagonal tile (I,K) of an eliminated column updates the diagonal tile (I,I) exactly once): stored from here,
       // the separate panel launch after the factorisation is gone
+      if (diag) ct_gstore_strip_block(a.L + (int64_t)cur_ai * CT_TT, bi, bj, lane, pa, -1.0);
+      acc = ct_mma_ra_bt(pa, diag ? XA : XB, bj, lane, acc);
+      if (diag && bj == 0) {
+        // r_I -= P' r_K: every lane holds eight elements of its row of P'; the four lanes of a row meet through two bpermutes
+        const int lr = lane >> 4;
+        double ps = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) ps = fma(-pa[kk], S.wk[lr + 4 * kk], ps);
+        ps += __shfl_xor(ps, 16, 64);
+        ps += __shfl_xor(ps, 32, 64);
+        if (lr == 0) S.part[0][16 * bi + (lane & 15)] = ps;
+      }
+    }
+#else
+      const ct_d4 p = ct_mma_abt<false>(XA, LI, bi, bj, lane, zero);   // T^-1 is stored exactly symmetric
       if (diag) ct_gstore_frag(a.L + (int64_t)cur_ai * CT_TT, bi, bj, lane, p);
       __syncthreads();                   // every wave has finished LI
       ct_store_frag(LI, bi, bj, lane, p);
@@ -1039,7 +1157,14 @@ __device__ __forceinline__ void ct_run_task(const CholLevelArgs& a, const FwdTas
         S.part[kg][i] = ps;
       }
     }
+#endif
     __syncthreads();                     // the operands are no longer read; the partial rhs products are complete
+#if CT_PSTRIP == 2
+    // the two waves of a tile row add their partials: each leaves what it gathered for the OTHER wave's block in XB, once per task
+    ct_store_frag(XB, bi, 1 - bj, lane, acc2[1 - bj]);
+    __syncthreads();
+    acc = acc2[bj] + ct_load_frag(XB, bi, bj, lane);
+#endif
     if (diag && !(t.kind & FK_FINAL)) rhs_fold();   // (a finalising task folds its last source AFTER the inverse: off the chain)
   }
   CT_STAMP(2);

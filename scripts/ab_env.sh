@@ -1,13 +1,16 @@
 #!/bin/bash
-# A/B of one environment switch on ONE box: alternating bench runs (LM leg only), value + ms per step of each
-# usage: scripts/ab_env.sh OUT VAR VALUE_A VALUE_B [rounds]
-out=$1; var=$2; a=$3; b=$4; n=${5:-3}
-: > "$out"
-for i in $(seq 1 "$n"); do
-  for v in "$a" "$b"; do
-    env "$var=$v" timeout 300 python bench.py --no-cpu-baseline --no-frontend 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$var=$v', round(d['value'],1), 'it/s', round(d['ms_per_step'],4), 'ms', d['config'].get('lambda_search'))" >> "$out"
+# A/B of environment knobs on one box: scripts/ab_env.sh OUT CONFIGS ROUNDS "ENV=VAL ..." "ENV=VAL ..." ...   ("-" = the default)
+out=$1; cfgs=$2; rounds=$3; shift 3
+for cfg in $cfgs; do
+  for i in $(seq $rounds); do
+    for v in "$@"; do
+      ev=$v; [ "$v" = "-" ] && ev=""
+      env $ev python bench.py --config $cfg --no-cpu-baseline --no-frontend 2> /dev/null | V="$v" C=$cfg python -c '
+import json,sys,os
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+q=d["config"]["lambda_search"]
+print("config %s %-28s %.1f it/s  %.4f ms/step  chol %.2f us  solves %d/%d  err %.12g" % (os.environ["C"], os.environ["V"]+":", d["value"], d["ms_per_step"], d["roofline"]["avg_launch_us"], q["solves_used"], q["solves_queued"], d["config"]["error_after"]))' >> $out
+    done
   done
 done
-cat "$out"
+cat $out

@@ -37,6 +37,11 @@ class TrackerParams:                      # TrackerParams.hpp:97-123 defaults
     ransac_threshold: float = 5.0         # :632
     use_clahe_filter: bool = True         # TrackerParams.hpp:101
     use_subpixel_corner_refinement: bool = True   # :99
+    feature_detector_type: int = 0        # TrackerParams::FeatureDetectorType (:48-52): 0 GFTT, 1 ORB_SLAM_ORB, 2 GFFT_CUDA (= GFTT)
+    orb_scale_factor: float = 1.2         # OrbParams (:88-93)
+    orb_n_levels: int = 8
+    orb_init_threshold_fast: int = 20
+    orb_min_threshold_fast: int = 7
 
 
 @dataclass
@@ -86,9 +91,18 @@ class KltFeatureTracker:
         want = p.max_features_per_frame - len(current)
         if want <= 0:
             return current
-        c = self.t.detect_corners(frame, mask, p.max_nr_keypoints_before_anms, p.quality_level,
-                                  float(p.min_distance_btw_tracked_and_detected_static_features), use_clahe=p.use_clahe_filter)
         use_anms = getattr(self, "use_anms", False)
+        if p.feature_detector_type == 1:
+            # FunctionalDetector::Create<ORBextractor> (FeatureDetector.cc:124-145): the mask does not reach the extractor; suppressNonMax
+            # orders the keypoints by (int)response, descending, in front of ANMS (NonMaximumSupression.cc:45-57)
+            k = self.t.detect_orb(frame, p.max_nr_keypoints_before_anms, p.orb_scale_factor, p.orb_n_levels, p.orb_init_threshold_fast,
+                                  p.orb_min_threshold_fast, use_clahe=p.use_clahe_filter, want_angle=False)
+            c = k["pt"]
+            if use_anms:
+                c = c[np.argsort(-k["response"].astype(np.int64), kind="stable")]
+        else:
+            c = self.t.detect_corners(frame, mask, p.max_nr_keypoints_before_anms, p.quality_level,
+                                      float(p.min_distance_btw_tracked_and_detected_static_features), use_clahe=p.use_clahe_filter)
         if use_anms:
             # SparseFeatureDetector::detect (FeatureDetector.cc:196-218): AdaptiveNonMaximumSuppression(RangeTree), tolerance 0.1,
             # max_features_per_frame - number_tracked corners, BEFORE the contained / shrunken / background tests of :391-412

@@ -1,0 +1,128 @@
+"""The ORB-SLAM extractor oracle (oracle/orb_oracle.py) against what can be checked without the OpenCV binary: the constants ORB-SLAM
+publishes (the umax table of the 31-pixel patch, the features-per-level split of its shipped settings), the textbook definition of the FAST
+9-16 test and score restated by brute force, cv::resize's fixed-point form against exact bilinear interpolation, and the invariants of
+DistributeOctTree.  CPU only."""
+import math
+
+import numpy as np
+import pytest
+
+from oracle import orb_oracle as O
+
+
+def test_constructor_tables_are_orb_slams():
+    P = O.OrbParams(1000, 1.2, 8, 20, 7)              # ORB-SLAM2's shipped settings (ORBextractor.nFeatures: 1000, scaleFactor 1.2, nLevels 8)
+    assert P.per_level == [217, 181, 151, 126, 105, 87, 73, 60] and sum(P.per_level) == 1000
+    assert P.umax == [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]          # the circular patch of radius 15
+    Q = O.OrbParams()                                  # the reference's: max_nr_keypoints_before_anms = 2000 (FeatureDetector.cc:130)
+    assert sum(Q.per_level) == 2000 and Q.per_level[0] == 434
+    assert [float(s) for s in Q.scale[:3]] == [1.0, float(np.float32(1.2)), float(np.float32(float(np.float32(1.2)) * float(np.float32(1.2))))]
+
+
+def test_resize_fixed_point_against_exact_bilinear():
+    rng = np.random.default_rng(0)
+    src = rng.integers(0, 256, (97, 131)).astype(np.uint8)
+    assert np.array_equal(O.resize_linear_u8(src, 131, 97), src)                              # same size: weights (2048, 0)
+    assert np.array_equal(O.resize_linear_u8(np.full((50, 60), 77, np.uint8), 50, 42), np.full((42, 50), 77, np.uint8))
+    dw, dh = O.cv_round(np.float32(131) / np.float32(1.2)), O.cv_round(np.float32(97) / np.float32(1.2))
+    got = O.resize_linear_u8(src, dw, dh).astype(np.float64)
+    # cv::resize's sampling: source coordinate (d + 0.5) * scale - 0.5, clamped at the border
+    fx = np.clip((np.arange(dw) + 0.5) * (131 / dw) - 0.5, 0, 130); fy = np.clip((np.arange(dh) + 0.5) * (97 / dh) - 0.5, 0, 96)
+    x0, y0 = np.floor(fx).astype(int), np.floor(fy).astype(int)
+    x1, y1 = np.minimum(x0 + 1, 130), np.minimum(y0 + 1, 96)
+    ax, ay = fx - x0, (fy - y0)[:, None]
+    s = src.astype(np.float64)
+    exact = (s[y0][:, x0] * (1 - ax) + s[y0][:, x1] * ax) * (1 - ay) + (s[y1][:, x0] * (1 - ax) + s[y1][:, x1] * ax) * ay
+    assert np.abs(got - exact).max() <= 1.0                                                    # 11-bit weights, truncating shifts
+    half = O.resize_linear_u8(src[:, :130], 65, 97).astype(int)                                # exactly 2:1 -> the mean of the pair
+    pair = (src[:, 0:130:2].astype(int) + src[:, 1:130:2].astype(int)) / 2
+    assert np.abs(half - pair).max() <= 0.5
+
+
+def _is_corner_brute(img, x, y, t):
+    v = int(img[y, x])
+    ring = [int(img[y + dy, x + dx]) for dx, dy in O.RING]
+    for sign in (1, -1):
+        flags = [(sign * (r - v)) > t for r in ring]
+        run = best = 0
+        for f in flags + flags:
+            run = run + 1 if f else 0
+            best = max(best, run)
+        if best >= 9:
+            return True
+    return False
+
+
+def test_fast_score_is_the_largest_threshold_that_still_fires():
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (26, 30)).astype(np.uint8)
+    img[8:18, 8:20] = np.clip(img[8:18, 8:20].astype(int) // 4 + 180, 0, 255).astype(np.uint8)     # a bright, lightly textured block
+    for t in (7, 20, 45):
+        S = O.fast_scores(img, t)
+        assert (S[:3] == 0).all() and (S[-3:] == 0).all() and (S[:, :3] == 0).all() and (S[:, -3:] == 0).all()
+        for y in range(3, 23):
+            for x in range(3, 27):
+                c = _is_corner_brute(img, x, y, t)
+                assert (S[y, x] > 0) == c, (t, x, y)
+                if c:       # cornerScore: the largest threshold at which the pixel is still a corner
+                    assert _is_corner_brute(img, x, y, int(S[y, x])) and not _is_corner_brute(img, x, y, int(S[y, x]) + 1)
+                    assert S[y, x] >= t
+    k = O.fast_detect(img, 7)
+    S = O.fast_scores(img, 7)
+    assert k == sorted(k, key=lambda q: (q[1], q[0]))                                          # row by row, left to right
+    for (x, y, s) in k:
+        nb = S[y - 1:y + 2, x - 1:x + 2].copy(); nb[1, 1] = -1
+        assert s == S[y, x] and s > nb.max()
+    flat = np.full((20, 20), 90, np.uint8); flat[5:15, 5:15] = 200                             # equal scores along an ideal edge: none is a strict maximum
+    assert O.fast_detect(flat, 20) == []
+
+
+def test_oct_tree_invariants():
+    rng = np.random.default_rng(1)
+    pts = [(float(x), float(y), float(r)) for x, y, r in zip(rng.integers(0, 600, 3000), rng.integers(0, 440, 3000), rng.integers(7, 120, 3000))]
+    for n_want in (5, 120, 434, 5000):
+        kept = O.distribute_oct_tree(pts, 16, 16 + 608, 16, 16 + 448, n_want)
+        assert kept == O.distribute_oct_tree(pts, 16, 16 + 608, 16, 16 + 448, n_want)          # deterministic
+        assert all(k in pts for k in kept)
+        assert len(set((k[0], k[1]) for k in kept)) == len(kept)                               # one keypoint per node, nodes are disjoint
+        distinct = len(set((p[0], p[1]) for p in pts))
+        assert len(kept) >= min(n_want, 2000)                                                  # (3 000 spread keypoints: no pass stalls before that)
+        assert len(kept) <= max(n_want + 3, 2)                                                 # a division adds at most three nodes
+    # the reference stops as soon as a pass over the list does not add a node (:667-669), even where another division would separate two
+    # keypoints: three keypoints of which two share a quadrant come back as two, the better one of the shared node
+    few = [(283.0, 224.0, 50.0), (307.0, 267.0, 20.0), (453.0, 243.0, 95.0)]
+    assert sorted(O.distribute_oct_tree(few, 16, 624, 16, 464, 100)) == [(283.0, 224.0, 50.0), (453.0, 243.0, 95.0)]
+    same = [(10.0, 10.0, 5.0), (10.0, 10.0, 9.0), (300.0, 200.0, 3.0)]                         # all in one quadrant: one node, its best keypoint
+    assert O.distribute_oct_tree(same, 16, 624, 16, 464, 100) == [(10.0, 10.0, 9.0)]
+    apart = [(10.0, 10.0, 5.0), (600.0, 10.0, 9.0), (10.0, 400.0, 3.0), (600.0, 400.0, 4.0)]   # one per quadrant: all four
+    assert sorted(O.distribute_oct_tree(apart, 16, 624, 16, 464, 100)) == sorted(apart)
+
+
+def test_fast_atan2_is_opencvs_polynomial():
+    for y, x in ((1, 1), (1, -1), (-1, -1), (-1, 1), (0, 5), (5, 0), (3, 4), (-7, 2), (1e-3, 1e3), (123456, -654321)):
+        want = math.degrees(math.atan2(y, x)) % 360.0
+        assert abs(float(O.fast_atan2(y, x)) - want) < 0.02                                    # the degree-7 fit is good to ~0.01 degrees
+    assert float(O.fast_atan2(0, 0)) == 0.0
+
+
+def test_detect_on_a_textured_frame():
+    rng = np.random.default_rng(2)
+    n = rng.integers(0, 256, (242, 322)).astype(np.float64)
+    g = sum(n[dy:dy + 240, dx:dx + 320] for dy in range(3) for dx in range(3)) / 9              # 240 x 320 of box-filtered noise: plenty of corners
+    g = np.clip((g - 128) * 3 + 128, 0, 255).astype(np.uint8)
+    P = O.OrbParams(300, 1.2, 4, 20, 7)
+    pt, resp, octv, ang, size = O.detect(g, P)
+    assert 300 <= len(pt) <= 300 + 3 * 4
+    assert (np.diff(octv) >= 0).all() and set(octv.tolist()) == {0, 1, 2, 3}                   # levels concatenated in order
+    for l in range(4):
+        s = float(P.scale[l])
+        m = octv == l
+        assert m.sum() >= P.per_level[l]
+        assert (pt[m, 0] >= 16 * s - 1e-3).all() and (pt[m, 0] < (round(320 / s) - 16) * s + 1e-3).all()      # inside the FAST border of the level
+        assert (size[m] == int(np.float32(31) * P.scale[l])).all()
+    assert (resp >= 7).all() and (resp <= 254).all() and ((ang >= 0) & (ang < 360)).all()
+    order = O.response_order(resp)
+    r = resp[order].astype(int)
+    assert (np.diff(r) <= 0).all()
+    for v in np.unique(r):                                                                      # equal responses keep their order
+        assert (np.diff(order[r == v]) > 0).all()

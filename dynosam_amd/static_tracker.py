@@ -42,6 +42,13 @@ class TrackerParams:                      # TrackerParams.hpp:97-123 defaults
     orb_n_levels: int = 8
     orb_init_threshold_fast: int = 20
     orb_min_threshold_fast: int = 7
+    gfft_block_size: int = 3              # GFFTParams (:72-80)
+    gfft_use_harris_corner_detector: bool = False
+    gfft_k: float = 0.04
+    anms_type: int = 4                    # AnmsParams (:55-63): AnmsAlgorithmType, RangeTree
+    anms_nr_horizontal_bins: int = 5
+    anms_nr_vertical_bins: int = 5
+    anms_binning_mask: object = None      # [nr_vertical_bins, nr_horizontal_bins] of 0 / 1 (Binning only)
 
 
 @dataclass
@@ -97,17 +104,18 @@ class KltFeatureTracker:
             # orders the keypoints by (int)response, descending, in front of ANMS (NonMaximumSupression.cc:45-57)
             k = self.t.detect_orb(frame, p.max_nr_keypoints_before_anms, p.orb_scale_factor, p.orb_n_levels, p.orb_init_threshold_fast,
                                   p.orb_min_threshold_fast, use_clahe=p.use_clahe_filter, want_angle=False)
-            c = k["pt"]
-            if use_anms:
-                c = c[np.argsort(-k["response"].astype(np.int64), kind="stable")]
+            c, resp = k["pt"], k["response"]
         else:
             c = self.t.detect_corners(frame, mask, p.max_nr_keypoints_before_anms, p.quality_level,
-                                      float(p.min_distance_btw_tracked_and_detected_static_features), use_clahe=p.use_clahe_filter)
+                                      float(p.min_distance_btw_tracked_and_detected_static_features), block_size=p.gfft_block_size,
+                                      use_harris=p.gfft_use_harris_corner_detector, k=p.gfft_k, use_clahe=p.use_clahe_filter)
+            resp = None
         if use_anms:
-            # SparseFeatureDetector::detect (FeatureDetector.cc:196-218): AdaptiveNonMaximumSuppression(RangeTree), tolerance 0.1,
-            # max_features_per_frame - number_tracked corners, BEFORE the contained / shrunken / background tests of :391-412
-            from .flow import anms_range_tree
-            c = c[anms_range_tree(c, want, 0.1, motion_mask.shape[1], motion_mask.shape[0])]
+            # SparseFeatureDetector::detect (FeatureDetector.cc:196-218): AdaptiveNonMaximumSuppression(anms_params.non_max_suppression_type), tolerance
+            # 0.1, max_features_per_frame - number_tracked corners, BEFORE the contained / shrunken / background tests of :391-412
+            from .flow import anms_suppress
+            c = c[anms_suppress(c, resp, want, 0.1, motion_mask.shape[1], motion_mask.shape[0], p.anms_type, p.anms_nr_horizontal_bins,
+                                p.anms_nr_vertical_bins, p.anms_binning_mask)]
         if p.use_subpixel_corner_refinement and len(c):
             c = self.t.corner_subpix(c, frame=frame, use_clahe=p.use_clahe_filter)      # FeatureDetector.cc:224-238
         c = c.astype(np.float64)

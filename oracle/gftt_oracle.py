@@ -30,7 +30,8 @@ def _reflect101(i, n):
     return np.where(i >= n, p - i, i)
 
 
-def min_eigen_val(gray: np.ndarray) -> np.ndarray:
+def min_eigen_val(gray: np.ndarray, block_size: int = 3, use_harris: bool = False, k: float = 0.04) -> np.ndarray:
+    """cornerMinEigenVal (or, use_harris, cornerHarris) with Sobel aperture 3 and a block_size x block_size box (anchor block_size // 2)"""
     h, w = gray.shape
     g = gray.astype(np.int64)
     ys, xs = np.arange(h), np.arange(w)
@@ -39,23 +40,28 @@ def min_eigen_val(gray: np.ndarray) -> np.ndarray:
     sm_x = g[:, xl] + 2 * g + g[:, xr]
     dxi = sm_y[:, xr] - sm_y[:, xl]
     dyi = sm_x[yd] - sm_x[yu]
-    scale = f32(1.0 / (4.0 * 3.0 * 255.0))
+    scale = f32(1.0 / (4.0 * float(block_size) * 255.0))
     dx, dy = dxi.astype(f32) * scale, dyi.astype(f32) * scale
     cxx, cxy, cyy = dx * dx, dx * dy, dy * dy
+    a0 = block_size // 2
     def box(c):
         acc = np.zeros((h, w), f32)
-        for oy in (-1, 0, 1):
-            for ox in (-1, 0, 1):
+        for oy in range(-a0, block_size - a0):
+            for ox in range(-a0, block_size - a0):
                 acc = (acc + c[_reflect101(ys + oy, h)][:, _reflect101(xs + ox, w)]).astype(f32)
         return acc
+    if use_harris:      # calcHarris: a c - b^2 - k (a + c)^2, every operation in fp32
+        a, b, c = box(cxx), box(cxy), box(cyy)
+        s = a + c
+        return ((a * c - b * b) - (f32(k) * s) * s).astype(f32)
     a, b, c = box(cxx) * f32(0.5), box(cxy), box(cyy) * f32(0.5)
     amc = a - c
     return ((a + c) - np.sqrt(amc * amc + b * b, dtype=f32)).astype(f32)
 
 
-def good_features_to_track(gray, mask=None, max_corners=2000, quality_level=0.001, min_distance=8.0):
+def good_features_to_track(gray, mask=None, max_corners=2000, quality_level=0.001, min_distance=8.0, block_size=3, use_harris=False, k=0.04):
     h, w = gray.shape
-    eig = min_eigen_val(gray)
+    eig = min_eigen_val(gray, block_size, use_harris, k)
     m = np.ones((h, w), bool) if mask is None else (np.asarray(mask) != 0)
     if not m.any():
         return np.zeros((0, 2), f32), eig

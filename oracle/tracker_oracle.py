@@ -84,6 +84,202 @@ def anms_range_tree(xy: np.ndarray, num_ret: int, tolerance: float, cols: int, r
         prevwidth = width
 
 
+def _c_round(v):
+    """C round(): half away from zero"""
+    return float(np.sign(v) * np.floor(abs(v) + 0.5))
+
+
+def _k_range(K, tolerance):
+    Kf, tol = np.float32(K), np.float32(tolerance)
+    return int(_c_round(float(Kf - Kf * tol))), int(_c_round(float(Kf + Kf * tol)))
+
+
+def anms_top_n(xy, num_ret):
+    """anms::TopN (anms.cc:67-78): the first num_ret keypoints of the list as it is handed over"""
+    n = len(xy)
+    return np.arange(n if num_ret > n else max(num_ret, 0), dtype=np.int64)
+
+
+def anms_brown(xy, num_ret):
+    """anms::BrownANMS (anms.cc:80-107): every keypoint's distance to the nearest EARLIER one (fp32), the num_ret largest radii.
+    (std::sort with `>` on the radius: equal radii in the list's order here)"""
+    xy = np.asarray(xy, np.float32).reshape(-1, 2)
+    n = len(xy)
+    if num_ret > n:
+        return np.arange(n, dtype=np.int64)
+    rad = np.full(n, np.finfo(np.float32).max, np.float32)
+    for i in range(1, n):
+        e1, e2 = xy[:i, 0] - xy[i, 0], xy[:i, 1] - xy[i, 1]
+        rad[i] = np.sqrt(e1 * e1 + e2 * e2, dtype=np.float32).min()
+    order = np.argsort(-rad.astype(np.float64), kind="stable")
+    return order[:max(num_ret, 0)].astype(np.int64)
+
+
+def _grid_cover(xy, n, cols, rows, c, reach, disc):
+    """the covering pass Sdc and Ssc share: cells of side c, a taken keypoint covers the cells within `reach` cells (a disc of that
+    radius in cell units when disc, else the square)"""
+    ncc, ncr = int(np.floor(cols / c)), int(np.floor(rows / c))
+    covered = np.zeros((ncr + 1, ncc + 1), bool)
+    result = []
+    fl = int(np.floor(reach))
+    for i in range(n):
+        row, col = int(np.floor(float(xy[i, 1]) / c)), int(np.floor(float(xy[i, 0]) / c))
+        if covered[row, col]:
+            continue
+        result.append(i)
+        r0, r1, c0, c1 = max(row - fl, 0), min(row + fl, ncr), max(col - fl, 0), min(col + fl, ncc)
+        if disc:
+            rr, cc = np.mgrid[r0:r1 + 1, c0:c1 + 1]
+            covered[r0:r1 + 1, c0:c1 + 1] |= np.sqrt(((rr - row) ** 2 + (cc - col) ** 2).astype(np.float64)) <= reach
+        else:
+            covered[r0:r1 + 1, c0:c1 + 1] = True
+    return result
+
+
+def anms_sdc(xy, num_ret, tolerance, cols, rows):
+    """anms::Sdc (anms.cc:109-186): suppression via disc covering, binary search over the radius in [1, cols]; as there, prevradius is
+    never updated - the search ends when low passes high"""
+    xy = np.asarray(xy, np.float32).reshape(-1, 2)
+    n = len(xy)
+    low, high = 1, cols
+    kmin, kmax = _k_range(num_ret, tolerance)
+    result = []
+    while True:
+        radius = low + int((high - low) / 2)
+        if radius == -1 or low > high:
+            return np.array(result, np.int64)
+        c = 0.25 * radius / np.sqrt(2.0)
+        result = _grid_cover(xy, n, cols, rows, c, radius / c, True)
+        if kmin <= len(result) <= kmax:
+            return np.array(result, np.int64)
+        if len(result) < kmin:
+            high = radius - 1
+        else:
+            low = radius + 1
+
+
+def _search_range(n, K, cols, rows):
+    exp1 = rows + cols + 2 * K
+    exp2 = 4 * cols + 4 * K + 4 * rows * K + rows * rows + cols * cols - 2 * rows * cols + 4 * rows * cols * K
+    exp3, exp4 = np.sqrt(float(exp2)), float(K - 1)
+    sol1, sol2 = -_c_round((exp1 + exp3) / exp4), -_c_round((exp1 - exp3) / exp4)
+    return int(np.floor(np.sqrt(float(n) / K))), int(sol1 if sol1 > sol2 else sol2)
+
+
+def anms_kdtree(xy, num_ret, tolerance, cols, rows):
+    """anms::KdTree (anms.cc:188-276): a taken keypoint excludes every keypoint whose truncated integer position lies closer than
+    the radius (nanoflann radiusSearch on squared distances, strictly smaller; the tree only answers that question)"""
+    xy = np.asarray(xy, np.float32).reshape(-1, 2)
+    n = len(xy)
+    low, high = _search_range(n, num_ret, cols, rows)
+    kmin, kmax = _k_range(num_ret, tolerance)
+    px, py = xy[:, 0].astype(np.int64), xy[:, 1].astype(np.int64)
+    result, prev = [], -1
+    while True:
+        radius = low + int((high - low) / 2)
+        if radius == prev or low > high:
+            return np.array(result, np.int64)
+        result = []
+        included = np.ones(n, bool)
+        for i in range(n):
+            if not included[i]:
+                continue
+            included[i] = False
+            result.append(i)
+            included &= ~(((px - px[i]) ** 2 + (py - py[i]) ** 2) < radius * radius)
+        if kmin <= len(result) <= kmax:
+            return np.array(result, np.int64)
+        if len(result) < kmin:
+            high = radius - 1
+        else:
+            low = radius + 1
+        prev = radius
+
+
+def anms_ssc(xy, num_ret, tolerance, cols, rows):
+    """anms::Ssc (anms.cc:364-475): suppression via square covering; cell side = width / 2 in INTEGER division (:425), the search also
+    ends at low >= high (:415-421).  A width of 1 makes the cell side 0 (the reference divides by it): ValueError here"""
+    xy = np.asarray(xy, np.float32).reshape(-1, 2)
+    n = len(xy)
+    low, high = _search_range(n, num_ret, cols, rows)
+    kmin, kmax = _k_range(num_ret, tolerance)
+    result, prev = [], -1
+    while True:
+        width = low + int((high - low) / 2)
+        if width == prev or low >= high:
+            return np.array(result, np.int64)
+        c = float(int(width / 2))
+        if c <= 0:
+            raise ValueError("anms::Ssc: cell side 0")
+        result = _grid_cover(xy, n, cols, rows, c, width / c, False)
+        if kmin <= len(result) <= kmax:
+            return np.array(result, np.int64)
+        if len(result) < kmin:
+            high = width - 1
+        else:
+            low = width + 1
+        prev = width
+
+
+def anms_binning(xy, num_ret, cols, rows, nr_horizontal_bins, nr_vertical_bins, binning_mask):
+    """AdaptiveNonMaximumSuppression::binning (NonMaximumSupression.cc:117-159): per active bin the first round(num_ret / active bins)
+    keypoints of the list"""
+    xy = np.asarray(xy, np.float32).reshape(-1, 2)
+    n = len(xy)
+    if num_ret > n:
+        return np.arange(n, dtype=np.int64)
+    mask = np.asarray(binning_mask, np.float64).reshape(nr_vertical_bins, nr_horizontal_bins)
+    bin_r, bin_c = np.float32(rows) / np.float32(nr_vertical_bins), np.float32(cols) / np.float32(nr_horizontal_bins)
+    active = np.float32(mask.sum())
+    if not active > 0:
+        raise ValueError("binning: no active bin")
+    per_bin = int(_c_round(float(np.float32(num_ret) / active)))
+    cnt = np.zeros((nr_vertical_bins, nr_horizontal_bins), np.int64)
+    out = []
+    for i in range(n):
+        r, c = int(xy[i, 1] / bin_r), int(xy[i, 0] / bin_c)
+        if mask[r, c] == 1 and cnt[r, c] < per_bin:
+            out.append(i)
+            cnt[r, c] += 1
+    return np.array(out, np.int64)
+
+
+ANMS_TYPES = {"TopN": 0, "BrownANMS": 1, "SDC": 2, "KdTree": 3, "RangeTree": 4, "Ssc": 5, "Binning": 6}      # AnmsAlgorithmType (NonMaximumSuppression.h:49-57)
+
+
+def suppress_non_max(xy, response, num_ret, tolerance, cols, rows, anms_type=4, nr_horizontal_bins=5, nr_vertical_bins=5, binning_mask=None):
+    """AdaptiveNonMaximumSuppression::suppressNonMax (NonMaximumSupression.cc:33-115): indices into xy of the kept keypoints, in the order
+    they are handed back.  The list is sorted by (int)response, descending (equal responses in their order; response None = all equal) -
+    except for TopN and BrownANMS, which the reference hands the UNSORTED list (:65,71)."""
+    xy = np.asarray(xy, np.float32).reshape(-1, 2)
+    n = len(xy)
+    if n == 0:
+        return np.zeros(0, np.int64)
+    order = np.arange(n) if response is None else np.argsort(-np.asarray(response).astype(np.int64), kind="stable")
+    if anms_type == 0:
+        return anms_top_n(xy, num_ret)
+    if anms_type == 1:
+        return anms_brown(xy, num_ret)
+    s = xy[order]
+    if anms_type in (2, 3, 5) and num_ret <= 0:
+        return np.zeros(0, np.int64)
+    if anms_type in (3, 5) and num_ret == 1:
+        return np.zeros(0, np.int64)          # the search range divides by num_ret - 1: (int)(-inf) = INT_MIN on x86, the search ends at once
+    if anms_type == 2:
+        k = anms_sdc(s, num_ret, tolerance, cols, rows)
+    elif anms_type == 3:
+        k = anms_kdtree(s, num_ret, tolerance, cols, rows)
+    elif anms_type == 4:
+        k = anms_range_tree(s, num_ret, tolerance, cols, rows)
+    elif anms_type == 5:
+        k = anms_ssc(s, num_ret, tolerance, cols, rows)
+    elif anms_type == 6:
+        k = anms_binning(s, num_ret, cols, rows, nr_horizontal_bins, nr_vertical_bins, binning_mask)
+    else:
+        raise ValueError(anms_type)
+    return order[k]
+
+
 def within_shrunken(x, y, w, h, shrink_row, shrink_col):
     """FeatureTrackerBase::isWithinShrunkenImage on (col, row) = static_cast<int>(kp)"""
     c, r = np.asarray(x).astype(np.int64), np.asarray(y).astype(np.int64)
@@ -385,8 +581,9 @@ def _usable_static(kp, motion_mask, shrink_row=0, shrink_col=0):
 
 
 def detect_static_features(gray, motion_mask, current, detection_mask, next_tracklet_id, max_features=400, max_before_anms=2000, quality_level=0.001,
-                           min_distance=8, shrink_row=0, shrink_col=0, use_anms=True, use_clahe=True, use_subpix=True, detector=0, orb=None):
-    """KltFeatureTracker::detectFeatures. current: dict(tracklet_id, kp [n,2] f64, age). returns (dict, next id).
+                           min_distance=8, shrink_row=0, shrink_col=0, use_anms=True, use_clahe=True, use_subpix=True, detector=0, orb=None, gfft=(3, False, 0.04),
+                           anms=(4, 5, 5, None)):
+    """KltFeatureTracker::detectFeatures.  anms = (AnmsAlgorithmType, nr_horizontal_bins, nr_vertical_bins, binning_mask). current: dict(tracklet_id, kp [n,2] f64, age). returns (dict, next id).
     detector: TrackerParams::FeatureDetectorType (0 GFTT, 1 ORB_SLAM_ORB with orb = orb_oracle.OrbParams or None = the defaults)"""
     from . import clahe_oracle as CO, gftt_oracle as GO, orb_oracle as OO, subpix_oracle as SO
     mask = np.full(motion_mask.shape, 255, np.uint8) if detection_mask is None else np.array(detection_mask, np.uint8)
@@ -401,12 +598,11 @@ def detect_static_features(gray, motion_mask, current, detection_mask, next_trac
     if detector == 1:
         # FeatureDetector.cc:124-145: keypoints only, no mask; NonMaximumSupression.cc:45-57: by (int)response, descending, in front of ANMS
         c, resp, _, _, _ = OO.detect(img, orb or OO.OrbParams(nfeatures=max_before_anms), with_angle=False)
-        if use_anms:
-            c = c[OO.response_order(resp)]
     else:
-        c, _ = GO.good_features_to_track(img, mask, max_before_anms, quality_level, float(min_distance))
+        c, _ = GO.good_features_to_track(img, mask, max_before_anms, quality_level, float(min_distance), *gfft)
+        resp = None                                                     # cv::GFTTDetector leaves KeyPoint::response at 0
     if use_anms:
-        c = c[anms_range_tree(c, want, 0.1, motion_mask.shape[1], motion_mask.shape[0])]
+        c = c[suppress_non_max(c, resp, want, 0.1, motion_mask.shape[1], motion_mask.shape[0], *anms)]
     if use_subpix and len(c):
         c, _ = SO.corner_sub_pix(img, c)
     c = c.astype(np.float64).reshape(-1, 2)
@@ -421,11 +617,12 @@ def detect_static_features(gray, motion_mask, current, detection_mask, next_trac
 
 def track_static_frame(previous, prev_gray, gray, motion_mask, detection_mask, next_tracklet_id, max_features=400, min_features=200, max_age=25,
                        max_before_anms=2000, quality_level=0.001, min_distance=8, shrink_row=0, shrink_col=0, use_anms=True, use_clahe=True,
-                       use_subpix=True, geometric_verification=True, ransac_threshold=5.0, R_km1_k=None, K=None, detector=0, orb=None):
+                       use_subpix=True, geometric_verification=True, ransac_threshold=5.0, R_km1_k=None, K=None, detector=0, orb=None, gfft=(3, False, 0.04),
+                       anms=(4, 5, 5, None)):
     """KltFeatureTracker::trackStatic. previous: None or dict(tracklet_id, kp, age). returns (features dict, outlier ids, info dict, next id)"""
     from . import klt_oracle as KO, ransac_oracle as RO
     kw = dict(max_features=max_features, max_before_anms=max_before_anms, quality_level=quality_level, min_distance=min_distance, shrink_row=shrink_row,
-              shrink_col=shrink_col, use_anms=use_anms, use_clahe=use_clahe, use_subpix=use_subpix, detector=detector, orb=orb)
+              shrink_col=shrink_col, use_anms=use_anms, use_clahe=use_clahe, use_subpix=use_subpix, detector=detector, orb=orb, gfft=gfft, anms=anms)
     info = dict(static_track_optical_flow=0, static_track_detections=0, new_static_detections=False, static_track_ransac_rejected=0)
     empty = dict(tracklet_id=np.zeros(0, np.int64), kp=np.zeros((0, 2)), age=np.zeros(0, np.int64))
     if previous is None or len(previous["tracklet_id"]) == 0:

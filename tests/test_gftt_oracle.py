@@ -52,3 +52,26 @@ def test_ties_prefer_the_higher_address():
     assert len(c) == 2
     i0, i1 = c[0, 1] * 96 + c[0, 0], c[1, 1] * 96 + c[1, 0]
     assert eig[int(c[0, 1]), int(c[0, 0])] == eig[int(c[1, 1]), int(c[1, 0])] and i0 > i1
+
+
+def test_block_size_and_harris_variants():
+    """TrackerParams::GFFTParams: a larger box only adds neighbours to the sums (block 1 = the pixel's own products), and the Harris response is
+    det - k trace^2 of the same sums"""
+    rng = np.random.default_rng(8)
+    g = rng.integers(0, 256, (40, 50)).astype(np.uint8)
+    e1, e3, e5 = G.min_eigen_val(g, 1), G.min_eigen_val(g, 3), G.min_eigen_val(g, 5)
+    assert e1.shape == e3.shape == e5.shape == g.shape
+    assert np.abs(e1).max() < 1e-6                                   # rank-one structure tensor of a single pixel: smaller eigenvalue 0 (up to fp32 rounding)
+    assert (e5[5:-5, 5:-5] * 25 >= e3[5:-5, 5:-5] * 9 - 1e-3).all()  # without the 1 / block_size^2 of the scaled products: more positive semi-definite terms, no smaller eigenvalue (Weyl)
+    hr = G.min_eigen_val(g, 3, True, 0.04)
+    # independent restatement in float64 from the same fp32 products
+    ys, xs = np.arange(40), np.arange(50)
+    gi = g.astype(np.int64)
+    r = lambda i, n: np.where(np.mod(i, 2 * (n - 1)) >= n, 2 * (n - 1) - np.mod(i, 2 * (n - 1)), np.mod(i, 2 * (n - 1)))
+    sy = gi[r(ys - 1, 40)] + 2 * gi + gi[r(ys + 1, 40)]; sx = gi[:, r(xs - 1, 50)] + 2 * gi + gi[:, r(xs + 1, 50)]
+    dx = (sy[:, r(xs + 1, 50)] - sy[:, r(xs - 1, 50)]) / (4 * 3 * 255.0); dy = (sx[r(ys + 1, 40)] - sx[r(ys - 1, 40)]) / (4 * 3 * 255.0)
+    box = lambda c: sum(c[r(ys + oy, 40)][:, r(xs + ox, 50)] for oy in (-1, 0, 1) for ox in (-1, 0, 1))
+    a, b, c = box(dx * dx), box(dx * dy), box(dy * dy)
+    assert np.abs(hr - (a * c - b * b - 0.04 * (a + c) ** 2)).max() < 1e-5
+    c1, _ = G.good_features_to_track(g, None, 50, 0.01, 3.0, 3, True, 0.04)
+    assert len(c1) > 5

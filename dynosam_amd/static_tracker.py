@@ -49,6 +49,8 @@ class TrackerParams:                      # TrackerParams.hpp:97-123 defaults
     anms_nr_horizontal_bins: int = 5
     anms_nr_vertical_bins: int = 5
     anms_binning_mask: object = None      # [nr_vertical_bins, nr_horizontal_bins] of 0 / 1 (Binning only)
+    subpix_window: tuple = (5, 5)         # SubPixelCornerRefinementParams (:64-69): window_size (width, height), half sizes
+    subpix_zero_zone: tuple = (-1, -1)
 
 
 @dataclass
@@ -117,7 +119,8 @@ class KltFeatureTracker:
             c = c[anms_suppress(c, resp, want, 0.1, motion_mask.shape[1], motion_mask.shape[0], p.anms_type, p.anms_nr_horizontal_bins,
                                 p.anms_nr_vertical_bins, p.anms_binning_mask)]
         if p.use_subpixel_corner_refinement and len(c):
-            c = self.t.corner_subpix(c, frame=frame, use_clahe=p.use_clahe_filter)      # FeatureDetector.cc:224-238
+            c = self.t.corner_subpix(c, frame=frame, use_clahe=p.use_clahe_filter, win=p.subpix_window[0], win_h=p.subpix_window[1],
+                                     zero_zone=p.subpix_zero_zone)      # FeatureDetector.cc:224-238
         c = c.astype(np.float64)
         c = c[self._usable(c, motion_mask)]
         if not use_anms:

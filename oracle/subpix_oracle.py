@@ -27,13 +27,20 @@ import numpy as np
 f32 = np.float32
 
 
-def weights(win=5):
-    n = 2 * win + 1
-    v = np.zeros(n, f32)
-    for i in range(n):
-        y = f32(f32(i - win) / f32(win))
-        v[i] = f32(math.exp(float(f32(-y * y))))
-    return (v[:, None] * v[None, :]).astype(f32)          # mask[i][j] = (float)(vy * exp(-x*x))
+def weights(win=5, win_h=None, zero_zone=(-1, -1)):
+    """mask[i][j] of cv::cornerSubPix: window half sizes (win, win_h) = (width, height), the zero zone's centre block set to 0"""
+    ww, wh = win, (win if win_h is None else win_h)
+    def axis(w):
+        v = np.zeros(2 * w + 1, f32)
+        for i in range(2 * w + 1):
+            y = f32(f32(i - w) / f32(w))
+            v[i] = f32(math.exp(float(f32(-y * y))))
+        return v
+    m = (axis(wh)[:, None] * axis(ww)[None, :]).astype(f32)          # mask[i][j] = (float)(vy * exp(-x*x))
+    zw, zh = zero_zone
+    if zw >= 0 and zh >= 0 and zw * 2 + 1 < 2 * ww + 1 and zh * 2 + 1 < 2 * wh + 1:
+        m[wh - zh:wh + zh + 1, ww - zw:ww + zw + 1] = 0
+    return m
 
 
 def get_rect_sub_pix(img: np.ndarray, size, center) -> np.ndarray:
@@ -75,14 +82,15 @@ def get_rect_sub_pix(img: np.ndarray, size, center) -> np.ndarray:
     return out
 
 
-def corner_sub_pix(img: np.ndarray, corners, win=5, max_count=40, epsilon=0.001):
-    """returns ([n, 2] f32 refined corners, [n] iterations used)"""
+def corner_sub_pix(img: np.ndarray, corners, win=5, max_count=40, epsilon=0.001, win_h=None, zero_zone=(-1, -1)):
+    """returns ([n, 2] f32 refined corners, [n] iterations used); (win, win_h) = SubPixelCornerRefinementParams::window_size (half sizes)"""
     img = np.ascontiguousarray(img, np.uint8)
     H, W = img.shape
-    n = 2 * win + 1
-    mask = weights(win).astype(np.float64)
-    px = (np.arange(n) - win).astype(np.float64)[None, :] * np.ones((n, 1))
-    py = (np.arange(n) - win).astype(np.float64)[:, None] * np.ones((1, n))
+    wh = win if win_h is None else win_h
+    wnx, wny = 2 * win + 1, 2 * wh + 1
+    mask = weights(win, wh, zero_zone).astype(np.float64)
+    px = (np.arange(wnx) - win).astype(np.float64)[None, :] * np.ones((wny, 1))
+    py = (np.arange(wny) - wh).astype(np.float64)[:, None] * np.ones((1, wnx))
     eps = max(epsilon, 0.0) ** 2
     max_iters = min(max(max_count, 1), 100)
     out = np.array(corners, f32).reshape(-1, 2).copy()
@@ -93,7 +101,7 @@ def corner_sub_pix(img: np.ndarray, corners, win=5, max_count=40, epsilon=0.001)
         cI = cT
         it = 0
         while True:
-            P = get_rect_sub_pix(img, (n + 2, n + 2), cI)
+            P = get_rect_sub_pix(img, (wnx + 2, wny + 2), cI)
             tgx = (P[1:-1, 2:] - P[1:-1, :-2]).astype(f32).astype(np.float64)
             tgy = (P[2:, 1:-1] - P[:-2, 1:-1]).astype(f32).astype(np.float64)
             gxx, gxy, gyy = tgx * tgx * mask, tgx * tgy * mask, tgy * tgy * mask
@@ -114,7 +122,7 @@ def corner_sub_pix(img: np.ndarray, corners, win=5, max_count=40, epsilon=0.001)
             if not (it < max_iters and err > eps):
                 break
         iters[k] = it
-        if abs(f32(cI[0] - cT[0])) > win or abs(f32(cI[1] - cT[1])) > win:
+        if abs(f32(cI[0] - cT[0])) > win or abs(f32(cI[1] - cT[1])) > wh:
             cI = cT
         out[k] = cI
     return out, iters

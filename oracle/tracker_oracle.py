@@ -582,8 +582,8 @@ def _usable_static(kp, motion_mask, shrink_row=0, shrink_col=0):
 
 def detect_static_features(gray, motion_mask, current, detection_mask, next_tracklet_id, max_features=400, max_before_anms=2000, quality_level=0.001,
                            min_distance=8, shrink_row=0, shrink_col=0, use_anms=True, use_clahe=True, use_subpix=True, detector=0, orb=None, gfft=(3, False, 0.04),
-                           anms=(4, 5, 5, None)):
-    """KltFeatureTracker::detectFeatures.  anms = (AnmsAlgorithmType, nr_horizontal_bins, nr_vertical_bins, binning_mask). current: dict(tracklet_id, kp [n,2] f64, age). returns (dict, next id).
+                           anms=(4, 5, 5, None), subpix=(5, 5, -1, -1)):
+    """KltFeatureTracker::detectFeatures.  subpix = (window half width, half height, zero zone width, height).  anms = (AnmsAlgorithmType, nr_horizontal_bins, nr_vertical_bins, binning_mask). current: dict(tracklet_id, kp [n,2] f64, age). returns (dict, next id).
     detector: TrackerParams::FeatureDetectorType (0 GFTT, 1 ORB_SLAM_ORB with orb = orb_oracle.OrbParams or None = the defaults)"""
     from . import clahe_oracle as CO, gftt_oracle as GO, orb_oracle as OO, subpix_oracle as SO
     mask = np.full(motion_mask.shape, 255, np.uint8) if detection_mask is None else np.array(detection_mask, np.uint8)
@@ -604,7 +604,7 @@ def detect_static_features(gray, motion_mask, current, detection_mask, next_trac
     if use_anms:
         c = c[suppress_non_max(c, resp, want, 0.1, motion_mask.shape[1], motion_mask.shape[0], *anms)]
     if use_subpix and len(c):
-        c, _ = SO.corner_sub_pix(img, c)
+        c, _ = SO.corner_sub_pix(img, c, subpix[0], win_h=subpix[1], zero_zone=(subpix[2], subpix[3]))
     c = c.astype(np.float64).reshape(-1, 2)
     c = c[_usable_static(c, motion_mask, shrink_row, shrink_col)]
     if not use_anms:
@@ -618,11 +618,11 @@ def detect_static_features(gray, motion_mask, current, detection_mask, next_trac
 def track_static_frame(previous, prev_gray, gray, motion_mask, detection_mask, next_tracklet_id, max_features=400, min_features=200, max_age=25,
                        max_before_anms=2000, quality_level=0.001, min_distance=8, shrink_row=0, shrink_col=0, use_anms=True, use_clahe=True,
                        use_subpix=True, geometric_verification=True, ransac_threshold=5.0, R_km1_k=None, K=None, detector=0, orb=None, gfft=(3, False, 0.04),
-                       anms=(4, 5, 5, None)):
+                       anms=(4, 5, 5, None), subpix=(5, 5, -1, -1)):
     """KltFeatureTracker::trackStatic. previous: None or dict(tracklet_id, kp, age). returns (features dict, outlier ids, info dict, next id)"""
     from . import klt_oracle as KO, ransac_oracle as RO
     kw = dict(max_features=max_features, max_before_anms=max_before_anms, quality_level=quality_level, min_distance=min_distance, shrink_row=shrink_row,
-              shrink_col=shrink_col, use_anms=use_anms, use_clahe=use_clahe, use_subpix=use_subpix, detector=detector, orb=orb, gfft=gfft, anms=anms)
+              shrink_col=shrink_col, use_anms=use_anms, use_clahe=use_clahe, use_subpix=use_subpix, detector=detector, orb=orb, gfft=gfft, anms=anms, subpix=subpix)
     info = dict(static_track_optical_flow=0, static_track_detections=0, new_static_detections=False, static_track_ransac_rejected=0)
     empty = dict(tracklet_id=np.zeros(0, np.int64), kp=np.zeros((0, 2)), age=np.zeros(0, np.int64))
     if previous is None or len(previous["tracklet_id"]) == 0:

@@ -65,3 +65,16 @@ def test_get_rect_sub_pix_paths_agree_in_the_interior():
             + a * b * g[iy + 1:iy + 14, ix + 1:ix + 14])
     assert np.abs(P - want).max() < 1e-3
     assert SO.weights().shape == (11, 11) and abs(SO.weights()[5, 5] - 1.0) < 1e-7 and abs(SO.weights()[0, 5] - np.exp(-1.0)) < 1e-6
+
+
+def test_other_windows_and_a_zero_zone():
+    """SubPixelCornerRefinementParams::window_size / zero_zone are configuration fields (TrackerParams.cc:63-68): a larger or non-square window still
+    finds the crossing, the zero zone only removes the centre's weights"""
+    img = _crossing(30.37, 28.81)
+    start = np.array([[31.0, 28.0]], np.float32)
+    for win, win_h, zz in ((5, None, (-1, -1)), (7, None, (-1, -1)), (4, 8, (-1, -1)), (6, 6, (1, 1)), (5, 5, (0, 0))):
+        out, it = SO.corner_sub_pix(img, start, win, win_h=win_h, zero_zone=zz)
+        assert abs(float(out[0, 0]) - 30.37) < 0.15 and abs(float(out[0, 1]) - 28.81) < 0.15, (win, win_h, zz, out)
+    m = SO.weights(6, 4, (1, 2))
+    assert m.shape == (9, 13) and (m[2:7, 5:8] == 0).all() and m[1, 6] > 0 and m[4, 4] > 0
+    assert (SO.weights(5, 5, (5, 5)) > 0).all()                     # a zero zone as large as the window is ignored (cornersubpix.cpp)

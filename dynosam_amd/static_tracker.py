@@ -151,7 +151,7 @@ class KltFeatureTracker:
             inl, _H, _best = self.t.verify_homography(previous.kp[gi].astype(np.float32), r["cur"][gi], self.p.ransac_threshold)
             good[gi[~inl]] = False
             self.info["static_track_ransac_rejected"] = int((~inl).sum())
-        outliers = previous.tracklet_id[~good]
+        outliers = np.sort(previous.tracklet_id[~good])      # determineOutlierIds (VisionTools.cc:744-764): a sorted set difference
         kp = r["cur"].astype(np.float64)
         keep = good & self._usable(kp, motion_mask_cur) & (previous.age + 1 <= self.p.max_feature_track_age)
         tracked = StaticFeatures(previous.tracklet_id[keep], kp[keep], previous.age[keep] + 1)

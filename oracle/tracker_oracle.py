@@ -280,6 +280,21 @@ def suppress_non_max(xy, response, num_ret, tolerance, cols, rows, anms_type=4, 
     return order[k]
 
 
+def determine_outlier_ids(inliers, tracklets):
+    """determineOutlierIds (dynosam/src/frontend/vision/VisionTools.cc:744-764): both lists sorted, outliers = tracklets \\ inliers by
+    std::set_difference - ascending ids whatever the order of the inputs.  Pinned by dynosam/test/test_tools.cc:41-68."""
+    a, b = sorted(int(t) for t in tracklets), sorted(int(t) for t in inliers)
+    out, j = [], 0
+    for t in a:                                   # std::set_difference on sorted ranges (multiset semantics)
+        while j < len(b) and b[j] < t:
+            j += 1
+        if j < len(b) and b[j] == t:
+            j += 1
+        else:
+            out.append(t)
+    return np.array(out, np.int64)
+
+
 def within_shrunken(x, y, w, h, shrink_row, shrink_col):
     """FeatureTrackerBase::isWithinShrunkenImage on (col, row) = static_cast<int>(kp)"""
     c, r = np.asarray(x).astype(np.int64), np.asarray(y).astype(np.int64)
@@ -639,7 +654,7 @@ def track_static_frame(previous, prev_gray, gray, motion_mask, detection_mask, n
         inl, _best, _H = RO.verify_homography(prev_kp[gi], cur[gi], ransac_threshold)
         good[gi[inl == 0]] = False
         info["static_track_ransac_rejected"] = int((inl == 0).sum())
-    outliers = previous["tracklet_id"][~good]
+    outliers = determine_outlier_ids(previous["tracklet_id"][good], previous["tracklet_id"])       # StaticFeatureTracker.cc:600-606
     kp = cur.astype(np.float64)
     keep = good & _usable_static(kp, motion_mask, shrink_row, shrink_col) & (previous["age"] + 1 <= max_age)
     tracked = dict(tracklet_id=previous["tracklet_id"][keep], kp=kp[keep], age=previous["age"][keep] + 1)

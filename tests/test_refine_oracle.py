@@ -50,3 +50,24 @@ def test_recovers_pose_and_rejects_gross_outliers():
     pr2["pose_init"] = to12(Xk2)
     res2 = R.FlowPoseProblem(K, pr2["X_prev"], pr2["pose_init"], pr2["kp_prev"], pr2["depth"], pr2["flow"]).optimize()
     assert res2["error_before"] < 1e-20 and res2["inlier"].all() and np.abs(res2["pose"] - to12(Xk2)).max() < 1e-12
+
+
+def test_camera_fixtures_of_the_reference():
+    """The pinhole projection / back-projection the refinement factors restate (oracle/refine_oracle.py _project / _backproject; the kernels carry
+    the same two formulas) against the reference's own Camera tests: dynosam/test/test_camera.cc:42-72 (project), :74-110 (back-projection at the
+    principal point of the default test camera, helpers.hpp:87-95), :112-140 (top-left corner with uneven focal lengths)."""
+    import numpy as np
+    from oracle import refine_oracle as RO
+    K = (1.0, 1.0, 0.0, 3.0, 2.0)                                                        # :51-57 fx, fy, u0, v0
+    lmks = [(0.0, 0.0, 1.0), (0.0, 0.0, 2.0), (0.0, 1.0, 2.0), (0.0, 10.0, 20.0), (1.0, 0.0, 2.0)]          # :44-48
+    want = [(3.0, 2.0), (3.0, 2.0), (3.0, 1.0 / 2.0 + 2.0), (3.0, 1.0 / 2.0 + 2.0), (1.0 / 2.0 + 3.0, 2.0)]  # :58-63
+    for P, kp in zip(lmks, want):
+        assert np.allclose(RO._project(K, np.array(P)), kp, atol=1e-12)
+    Kd = (554.256, 554.256, 0.0, 640 / 2, 480 / 2)                                       # helpers.hpp:87-95
+    for depth in (2.0, 3.0, 4.5):                                                         # :81-86, :98-108
+        assert np.allclose(RO._backproject(Kd, np.array([Kd[3], Kd[4]]), depth), [0.0, 0.0, depth], atol=1e-4)
+    fx, fy, cu, cv = 30.9 / 2.2, 12.0 / 23.0, 390.8, 142.2                               # :117-120
+    got = RO._backproject((fx, fy, 0.0, cu, cv), np.array([0.0, 0.0]), 2.0)              # :130-134
+    assert np.allclose(got, [2.0 / fx * (-cu), 2.0 / fy * (-cv), 2.0], atol=1e-4)        # :136-139
+    for P in lmks:                                                                        # the two are inverses of each other
+        assert np.allclose(RO._backproject(K, RO._project(K, np.array(P)), P[2]), P, atol=1e-12)

@@ -151,3 +151,22 @@ def test_propogate_mask_rules():
     o5, p5 = feats(5, 160)
     out6, done6 = TO.propogate_mask(np.concatenate([o3, o5]), np.concatenate([p3, p5]), prev, flow, cur)
     assert done6 == [3, 5] and (out6 == 5).sum() > 0 and (out6 == 3).sum() > 0
+
+
+def test_reference_fixtures_of_determine_outlier_ids_and_the_chi_square_quantile():
+    """Reference-held known answers on the tracker's path: determineOutlierIds (dynosam/test/test_tools.cc:41-68) - the outlier list of
+    KltFeatureTracker::trackPoints (StaticFeatureTracker.cc:600-606) - and chi_squared_quantile (dynosam/test/test_numerical.cc:38-50), whose
+    values at (2, 0.99) / (3, 0.99) are the outlier thresholds of the two per-object refinements (FactorGraphTools.hpp:81-90: 0.5 x the quantile)."""
+    import os
+    from scipy.stats import chi2
+    from oracle import refine_oracle as RO
+    from dynosam_amd import motion_refine as MR
+    assert TO.determine_outlier_ids([1, 2], [1, 2, 3, 4, 5]).tolist() == [3, 4, 5]                                  # :41-49
+    assert TO.determine_outlier_ids([3, 1, 100], [12, 45, 1, 85, 3, 100]).tolist() == [12, 45, 85]                  # :51-59 unordered inputs
+    assert TO.determine_outlier_ids([12, 45, 1, 85, 3, 100], [12, 45, 1, 85, 3, 100]).tolist() == []                # :61-68
+    assert chi2.ppf(0.99, 6) == pytest.approx(16.811893829770927, rel=1e-13)                                         # test_numerical.cc:42-43: boost == scipy here
+    assert chi2.ppf(0.5, 3) == pytest.approx(2.3659738843753377, rel=1e-13)                                          # :47-48
+    assert RO.CHI2_2_099 == pytest.approx(chi2.ppf(0.99, 2), rel=1e-14) and MR.CHI2_3_099 == pytest.approx(chi2.ppf(0.99, 3), rel=1e-14)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert "0.5 * 9.210340371976182" in open(os.path.join(root, "dynosam_amd", "csrc", "dynoflow.hip")).read()     # the constants the kernels carry
+    assert "0.5 * 11.344866730144373" in open(os.path.join(root, "dynosam_amd", "csrc", "motion_refine.h")).read()

@@ -342,6 +342,11 @@ def test_c_example_compiles():
     subprocess.run(["gcc", "-O2", "-Wall", "-Werror", "-std=gnu99", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "incremental_loop.c"), "-o", exe2, lib,
                     "-Wl,-rpath," + os.path.dirname(lib), "-Wl,--allow-shlib-undefined"], check=True)
     assert os.path.exists(exe2)
+    # examples/frontend_loop.c: FeatureTracker::track through include/dynoflow.h alone (renders its own image stream)
+    exe3 = os.path.join(root, "examples", "frontend_loop")
+    subprocess.run(["gcc", "-O2", "-Wall", "-Werror", "-std=gnu99", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "frontend_loop.c"), "-o", exe3, lib,
+                    "-Wl,-rpath," + os.path.dirname(lib), "-Wl,--allow-shlib-undefined", "-lm"], check=True)
+    assert os.path.exists(exe3)
 
 
 @pytest.mark.gpu
@@ -362,6 +367,20 @@ def test_c_example_runs_the_incremental_mode(tmp_path):
     n_marg = int(last.split("variables marginalised")[0].split(",")[-1].strip())
     calls = int(last.split(" hook calls")[0].split(",")[-1].strip())
     assert n_marg > 0 and calls >= 1, last
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode, det", [("flow", "gftt"), ("own", "gftt"), ("klt", "gftt"), ("flow", "orb")])
+def test_c_example_runs_the_frontend(mode, det):
+    """examples/frontend_loop.c: the frontend seam from plain C - the image container with its optical-flow image (`flow`), the library's own dense
+    flow (`own`) or the KLT fallback, GFTT or the ORB-SLAM detector.  The program renders a scene with known motion and checks the Frame it gets back
+    (static features on the background, dynamic ones on the object, tracked dynamic features moved by the object's flow): exit code 0"""
+    import subprocess
+    test_c_example_compiles()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([os.path.join(root, "examples", "frontend_loop"), "8", mode, det], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-800:])
+    assert "0 failed checks" in r.stdout.strip().splitlines()[-1]
 
 
 @pytest.mark.gpu

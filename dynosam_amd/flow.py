@@ -411,6 +411,7 @@ class FlowTracker:
                     inner_boxes=[tuple(int(io.inner_boxes[4 * k + e]) for e in range(4)) for k in range(n)])
 
 
+ANMS_STD_SORT = 0x100     # flag on the type: cv::sortIdx's generic path (std::sort, not stable) instead of IPP's stable radix sort (include/dynoflow.h)
 ANMS_TYPES = {"TopN": 0, "BrownANMS": 1, "SDC": 2, "KdTree": 3, "RangeTree": 4, "Ssc": 5, "Binning": 6}      # AnmsAlgorithmType (NonMaximumSuppression.h:49-57)
 
 

@@ -244,18 +244,106 @@ def anms_binning(xy, num_ret, cols, rows, nr_horizontal_bins, nr_vertical_bins, 
     return np.array(out, np.int64)
 
 
+def std_sort_indices(keys):
+    """libstdc++'s std::sort (bits/stl_algo.h: introsort - median-of-three to the front, unguarded Hoare partition, recursion on the right part, depth
+    limit 2 lg n, then one insertion-sort pass with the first 16 guarded) applied to the index array 0..n-1 with the comparator keys[a] < keys[b], as
+    cv::sortIdx's generic path does (modules/core/src/matrix_operations.cpp: sortIdx_ -> std::sort(iptr, iptr + len, LessThanIdx<T>(ptr))).  The sort is
+    not stable: WHERE equal keys end up is part of the reference's behaviour on OpenCV builds without IPP.  Pinned against g++'s own std::sort by
+    tests/test_anms_types.py.  (The heap-sort fallback behind the depth limit is not restated: it raises.)"""
+    k = [int(v) for v in keys]
+    a = list(range(len(k)))
+    less = lambda x, y: k[x] < k[y]
+
+    def unguarded_linear_insert(last):
+        val = a[last]
+        nxt = last - 1
+        while less(val, a[nxt]):
+            a[last] = a[nxt]
+            last = nxt
+            nxt -= 1
+        a[last] = val
+
+    def insertion_sort(first, last):
+        if first == last:
+            return
+        for i in range(first + 1, last):
+            if less(a[i], a[first]):
+                val = a[i]
+                a[first + 1:i + 1] = a[first:i]
+                a[first] = val
+            else:
+                unguarded_linear_insert(i)
+
+    def move_median_to_first(result, x, y, z):
+        if less(a[x], a[y]):
+            pick = y if less(a[y], a[z]) else (z if less(a[x], a[z]) else x)
+        elif less(a[x], a[z]):
+            pick = x
+        elif less(a[y], a[z]):
+            pick = z
+        else:
+            pick = y
+        a[result], a[pick] = a[pick], a[result]
+
+    def unguarded_partition(first, last, pivot):
+        while True:
+            while less(a[first], a[pivot]):
+                first += 1
+            last -= 1
+            while less(a[pivot], a[last]):
+                last -= 1
+            if not first < last:
+                return first
+            a[first], a[last] = a[last], a[first]
+            first += 1
+
+    def introsort_loop(first, last, depth):
+        while last - first > 16:
+            if depth == 0:
+                raise NotImplementedError("std::sort's heap-sort fallback")
+            depth -= 1
+            mid = first + (last - first) // 2
+            move_median_to_first(first, first + 1, mid, last - 1)
+            cut = unguarded_partition(first + 1, last, first)
+            introsort_loop(cut, last, depth)
+            last = cut
+
+    n = len(a)
+    if n:
+        introsort_loop(0, n, 2 * (n.bit_length() - 1))
+        if n > 16:
+            insertion_sort(0, 16)
+            for i in range(16, n):
+                unguarded_linear_insert(i)
+        else:
+            insertion_sort(0, n)
+    return np.array(a, np.int64)
+
+
+def sort_idx_descending(keys, std_sort=False):
+    """cv::sortIdx(keys, SORT_DESCENDING) on the row of (int) responses: IPP's radix sort where OpenCV is built with IPP (x86 defaults; equal keys keep
+    their order) or - std_sort - the generic path: std::sort ascending, then the index array reversed"""
+    k = np.asarray(keys).astype(np.int64)
+    if not std_sort:
+        return np.argsort(-k, kind="stable")
+    return std_sort_indices(k)[::-1].copy()
+
+
+ANMS_STD_SORT = 0x100     # flag on the ANMS type: the response sort as OpenCV's generic cv::sortIdx performs it (builds without IPP, e.g. docker/Dockerfile.l4t_jetpack6)
 ANMS_TYPES = {"TopN": 0, "BrownANMS": 1, "SDC": 2, "KdTree": 3, "RangeTree": 4, "Ssc": 5, "Binning": 6}      # AnmsAlgorithmType (NonMaximumSuppression.h:49-57)
 
 
 def suppress_non_max(xy, response, num_ret, tolerance, cols, rows, anms_type=4, nr_horizontal_bins=5, nr_vertical_bins=5, binning_mask=None):
     """AdaptiveNonMaximumSuppression::suppressNonMax (NonMaximumSupression.cc:33-115): indices into xy of the kept keypoints, in the order
-    they are handed back.  The list is sorted by (int)response, descending (equal responses in their order; response None = all equal) -
-    except for TopN and BrownANMS, which the reference hands the UNSORTED list (:65,71)."""
+    they are handed back.  The list is sorted by (int)response, descending (equal responses in their order - or, with the ANMS_STD_SORT flag on the
+    type, where std::sort leaves them; response None = all equal, cv::GFTTDetector's keypoints) - except for TopN and BrownANMS, which the reference
+    hands the UNSORTED list (:65,71)."""
     xy = np.asarray(xy, np.float32).reshape(-1, 2)
     n = len(xy)
     if n == 0:
         return np.zeros(0, np.int64)
-    order = np.arange(n) if response is None else np.argsort(-np.asarray(response).astype(np.int64), kind="stable")
+    std_sort, anms_type = bool(anms_type & ANMS_STD_SORT), anms_type & 0xFF
+    order = sort_idx_descending(np.zeros(n, np.int64) if response is None else np.asarray(response).astype(np.int64), std_sort)
     if anms_type == 0:
         return anms_top_n(xy, num_ret)
     if anms_type == 1:

@@ -101,8 +101,7 @@ def anms_top_n(xy, num_ret):
 
 
 def anms_brown(xy, num_ret):
-    """anms::BrownANMS (anms.cc:80-107): every keypoint's distance to the nearest EARLIER one (fp32), the num_ret largest radii.
-    (std::sort with `>` on the radius: equal radii in the list's order here)"""
+    """anms::BrownANMS (anms.cc:80-107): every keypoint's distance to the nearest EARLIER one (fp32), the num_ret largest radii"""
     xy = np.asarray(xy, np.float32).reshape(-1, 2)
     n = len(xy)
     if num_ret > n:
@@ -111,7 +110,9 @@ def anms_brown(xy, num_ret):
     for i in range(1, n):
         e1, e2 = xy[:i, 0] - xy[i, 0], xy[:i, 1] - xy[i, 1]
         rad[i] = np.sqrt(e1 * e1 + e2 * e2, dtype=np.float32).min()
-    order = np.argsort(-rad.astype(np.float64), kind="stable")
+    # sort(results.begin(), results.end(), sort_pred()) on (radius, index) pairs with `left.first > right.first`: std::sort, so keypoints of EQUAL
+    # radius (integer pixel positions make those common) come out in libstdc++'s order - sorting the pairs moves them exactly as sorting indices does
+    order = std_sort_indices([float(r) for r in rad], comp=lambda x, y: x > y)
     return order[:max(num_ret, 0)].astype(np.int64)
 
 
@@ -244,15 +245,16 @@ def anms_binning(xy, num_ret, cols, rows, nr_horizontal_bins, nr_vertical_bins, 
     return np.array(out, np.int64)
 
 
-def std_sort_indices(keys):
+def std_sort_indices(keys, comp=None):
     """libstdc++'s std::sort (bits/stl_algo.h: introsort - median-of-three to the front, unguarded Hoare partition, recursion on the right part, depth
     limit 2 lg n, then one insertion-sort pass with the first 16 guarded) applied to the index array 0..n-1 with the comparator keys[a] < keys[b], as
     cv::sortIdx's generic path does (modules/core/src/matrix_operations.cpp: sortIdx_ -> std::sort(iptr, iptr + len, LessThanIdx<T>(ptr))).  The sort is
     not stable: WHERE equal keys end up is part of the reference's behaviour on OpenCV builds without IPP.  Pinned against g++'s own std::sort by
-    tests/test_anms_types.py.  (The heap-sort fallback behind the depth limit is not restated: it raises.)"""
-    k = [int(v) for v in keys]
+    tests/test_anms_types.py.  (The heap-sort fallback behind the depth limit is not restated: it raises.)  comp(x, y): the strict weak order on
+    the keys, default x < y."""
+    k = list(keys)
     a = list(range(len(k)))
-    less = lambda x, y: k[x] < k[y]
+    less = (lambda x, y: k[x] < k[y]) if comp is None else (lambda x, y: comp(k[x], k[y]))
 
     def unguarded_linear_insert(last):
         val = a[last]
@@ -326,7 +328,7 @@ def sort_idx_descending(keys, std_sort=False):
     k = np.asarray(keys).astype(np.int64)
     if not std_sort:
         return np.argsort(-k, kind="stable")
-    return std_sort_indices(k)[::-1].copy()
+    return std_sort_indices([int(v) for v in k])[::-1].copy()
 
 
 ANMS_STD_SORT = 0x100     # flag on the ANMS type: the response sort as OpenCV's generic cv::sortIdx performs it (builds without IPP, e.g. docker/Dockerfile.l4t_jetpack6)

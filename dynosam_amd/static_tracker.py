@@ -85,7 +85,9 @@ class KltFeatureTracker:
         x, y = np.floor(kp[:, 0]).astype(int), np.floor(kp[:, 1]).astype(int)
         contained = (kp[:, 0] >= 0) & (kp[:, 0] < w) & (kp[:, 1] >= 0) & (kp[:, 1] < h)
         p = self.p
-        shrunk = (kp[:, 1] >= p.shrink_row) & (kp[:, 1] < h - p.shrink_row) & (kp[:, 0] >= p.shrink_col) & (kp[:, 0] < w - p.shrink_col)
+        # isWithinShrunkenImage (FeatureTrackerBase.cc:313-326): truncated coordinates, strict inequalities - row 0 / column 0 are outside even unshrunk
+        col, row = np.trunc(kp[:, 0]).astype(np.int64), np.trunc(kp[:, 1]).astype(np.int64)
+        shrunk = (row > p.shrink_row) & (row < h - p.shrink_row) & (col > p.shrink_col) & (col < w - p.shrink_col)
         ok = contained & shrunk
         ok[ok] &= motion_mask[y[ok], x[ok]] == 0
         return ok

@@ -679,7 +679,7 @@ Undefined in the reference and fixed here (and in the product): objects are samp
 def _usable_static(kp, motion_mask, shrink_row=0, shrink_col=0):
     h, w = motion_mask.shape
     ok = (kp[:, 0] >= 0) & (kp[:, 0] < w) & (kp[:, 1] >= 0) & (kp[:, 1] < h)
-    ok &= (kp[:, 1] >= shrink_row) & (kp[:, 1] < h - shrink_row) & (kp[:, 0] >= shrink_col) & (kp[:, 0] < w - shrink_col)
+    ok &= within_shrunken(kp[:, 0], kp[:, 1], w, h, shrink_row, shrink_col)         # FeatureTrackerBase.cc:313-326: truncated coordinates, STRICT inequalities
     x, y = np.floor(kp[:, 0]).astype(int), np.floor(kp[:, 1]).astype(int)
     ok[ok] &= motion_mask[y[ok], x[ok]] == 0
     return ok

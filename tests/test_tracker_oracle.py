@@ -170,3 +170,18 @@ def test_reference_fixtures_of_determine_outlier_ids_and_the_chi_square_quantile
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     assert "0.5 * 9.210340371976182" in open(os.path.join(root, "dynosam_amd", "csrc", "dynoflow.hip")).read()     # the constants the kernels carry
     assert "0.5 * 11.344866730144373" in open(os.path.join(root, "dynosam_amd", "csrc", "motion_refine.h")).read()
+
+
+def test_the_static_half_uses_the_reference_shrunken_image_test():
+    """KltFeatureTracker::detectFeatures / trackPoints keep a keypoint when camera_->isKeypointContained(kp) && isWithinShrunkenImage(kp)
+    (StaticFeatureTracker.cc:402,586).  isWithinShrunkenImage (FeatureTrackerBase.cc:313-326) casts the coordinates to int (functional_keypoint::u / v,
+    dynosam_cv/include/dynosam_cv/Feature.hpp:46-55) and compares STRICTLY: row > shrink_row && row < rows - shrink_row && col > shrink_col && col <
+    cols - shrink_col - so even without shrinking the first row and column are outside."""
+    mask = np.zeros((48, 64), np.int32)
+    kp = np.array([[0.5, 10.5], [10.5, 0.5], [1.0, 1.0], [0.99, 5.0], [63.5, 5.0], [62.9, 46.9], [5.0, 47.2], [30.0, 20.0]])
+    assert TO._usable_static(kp, mask, 0, 0).tolist() == [False, False, True, False, True, True, True, True]
+    kp = np.array([[10.0, 5.99], [10.0, 6.0], [10.0, 6.99], [10.0, 7.0], [8.9, 20.0], [9.0, 20.0], [55.99, 20.0], [56.0, 20.0], [30.0, 41.0], [30.0, 42.0]])
+    #      shrink_row 6, shrink_col 8 on 64 x 48:   rows 7..41, columns 9..55 remain
+    assert TO._usable_static(kp, mask, 6, 8).tolist() == [False, False, False, True, False, True, True, False, True, False]
+    mask[20, 30] = 2
+    assert not TO._usable_static(np.array([[30.4, 20.7]]), mask, 0, 0)[0]                       # motion_mask.at<int>(v, u) != background

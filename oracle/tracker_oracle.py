@@ -711,9 +711,7 @@ def detect_static_features(gray, motion_mask, current, detection_mask, next_trac
     if use_subpix and len(c):
         c, _ = SO.corner_sub_pix(img, c, subpix[0], win_h=subpix[1], zero_zone=(subpix[2], subpix[3]))
     c = c.astype(np.float64).reshape(-1, 2)
-    c = c[_usable_static(c, motion_mask, shrink_row, shrink_col)]
-    if not use_anms:
-        c = c[:want]
+    c = c[_usable_static(c, motion_mask, shrink_row, shrink_col)]      # (without ANMS every raw keypoint: FeatureDetector.cc:201-222)
     ids = next_tracklet_id + np.arange(len(c), dtype=np.int64)
     out = dict(tracklet_id=np.concatenate([current["tracklet_id"], ids]), kp=np.concatenate([current["kp"].reshape(-1, 2), c]),
                age=np.concatenate([current["age"], np.zeros(len(c), np.int64)]))

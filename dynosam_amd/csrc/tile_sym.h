@@ -101,22 +101,9 @@ struct TileSym {
   std::vector<BwdPush> bpush;
   std::vector<BwdSrc> bsrc;
   std::vector<BwdLaunch> blaunch;   // [n_blaunch+1]; launch q finalises level (n_levels-1-q)
-  // Dataflow form of the same schedule (k_chol_dataflow): the tasks keep their order (a topological order: a task only reads
-  // what tasks before it wrote), but instead of one launch per level every task waits for exactly its own inputs.
-  //   task_seq[i]  ordinal of task i among the tasks that write its target tile (tasks on one tile apply in list order);
-  //                for a row task the ordinals of its items' targets are in src_seq[src0 + j]
-  //   tile_need[t] number of tasks that write tile t: a tile is FINAL (readable as a source operand) once that many are done
-  std::vector<int32_t> task_seq, src_seq, tile_need;
-  // ... and what every task waits for, flattened: (word, want) pairs over ONE counter array [tile_done (n_tiles) | col_done (nt)];
-  // the first DF_INLINE pairs ride in the task's DfDeps record (one memory round trip after the ticket), the rest in df_more
-  static constexpr int DF_INLINE = 7;
-  struct DfDeps { int32_t n, more0; uint32_t w[DF_INLINE], v[DF_INLINE]; };
-  std::vector<DfDeps> df_deps;
-  std::vector<uint32_t> df_more;   // pairs (word, want)
   double flops_factor = 0;        // fp64 flops of one numeric factorisation incl. the redundant panel re-derivations
   bool two_phase = false;         // with n_elim >= 0: ALSO schedule the remaining columns as a second phase
   std::vector<int32_t> phase_end; // index into flaunch where each phase's launches end
-  bool want_df = true;
   int bitmap_max_nt = 8192;       // structure de-duplication through one bit per tile up to this many tile columns (8 MB), a sort of the list above
   int n_elim = -1;                // >= 0: PARTIAL factorisation — only tile columns < n_elim are eliminated; the trailing
                                   // tiles are left holding the Schur complement (marginalisation, SlidingWindowOptimization.cc:157-188)
@@ -130,10 +117,8 @@ struct TileSym {
   int32_t diag(int J) const { return col_ptr[J]; }
 
   // lower: list of (I,J), I >= J, tiles holding a structural non-zero of S (duplicates allowed)
-  // want_df: also build the per-task dependency lists of the dataflow form (k_chol_dataflow); the level launches do not read them
-  void analyse(int nt_, std::vector<std::pair<int32_t, int32_t>> lower, bool schedule = true, int n_elim_ = -1, bool two_phase_ = false, bool want_df_ = true) {
+  void analyse(int nt_, std::vector<std::pair<int32_t, int32_t>> lower, bool schedule = true, int n_elim_ = -1, bool two_phase_ = false) {
     nt = nt_;
-    want_df = want_df_;
     n_elim = n_elim_;
     two_phase = two_phase_;
     std::vector<std::vector<int32_t>> rows(nt);
@@ -205,47 +190,6 @@ struct TileSym {
       build_phase(ph.first, ph.second);
       phase_end.push_back((int32_t)flaunch.size() - 1);
     }
-    task_seq.assign(ftask.size(), 0); src_seq.assign(fsrc.size(), 0); tile_need.assign((size_t)n_tiles + (size_t)n_scratch, 0);
-    for (size_t i = 0; i < ftask.size(); ++i) {
-      const FwdTask& f = ftask[i];
-      if (f.kind & FK_ROW) { for (int j = 0; j < f.nsrc; ++j) src_seq[f.src0 + j] = tile_need[fsrc[f.src0 + j].ai]++; }
-      else task_seq[i] = tile_need[f.tgt]++;
-    }
-    df_deps.assign(want_df ? ftask.size() : 1, DfDeps{});
-    df_more.clear();
-    for (size_t i = 0; want_df && i < ftask.size(); ++i) {
-      const FwdTask& f = ftask[i];
-      std::vector<std::pair<uint32_t, uint32_t>> d;
-      auto add = [&](uint32_t word, uint32_t want) {
-        if (want == 0) return;
-        for (auto& e : d) if (e.first == word) { e.second = std::max(e.second, want); return; }
-        d.push_back({word, want});
-      };
-      if (f.kind & FK_ROW) {
-        add((uint32_t)f.ai0, (uint32_t)tile_need[f.ai0]);
-        add((uint32_t)(n_tiles + f.k0), 1u);
-        for (int j = 0; j < f.nsrc; ++j) {
-          const FwdSrc& it = fsrc[f.src0 + j];
-          add((uint32_t)it.ai, (uint32_t)src_seq[f.src0 + j]);
-          add((uint32_t)it.aj, (uint32_t)tile_need[it.aj]);
-        }
-      } else {
-        add((uint32_t)f.tgt, (uint32_t)task_seq[i]);
-        for (int q = 0; q < f.nsrc; ++q) {
-          const FwdSrc& sc = fsrc[f.src0 + q];
-          add((uint32_t)(n_tiles + sc.k), 1u);          // (first: the column result is what arrives last)
-          add((uint32_t)sc.ai, (uint32_t)tile_need[sc.ai]);
-          add((uint32_t)sc.aj, (uint32_t)tile_need[sc.aj]);
-        }
-      }
-      DfDeps& D = df_deps[i];
-      D.n = (int32_t)d.size(); D.more0 = (int32_t)(df_more.size() / 2);
-      for (size_t k = 0; k < d.size(); ++k) {
-        if (k < (size_t)DF_INLINE) { D.w[k] = d[k].first; D.v[k] = d[k].second; }
-        else { df_more.push_back(d[k].first); df_more.push_back(d[k].second); }
-      }
-    }
-    if (df_more.empty()) df_more.assign(2, 0u);
     panel.clear();
     for (int K = 0; K < phases.back().second; ++K)
       for (int32_t x = col_ptr[K] + 1; x < col_ptr[K + 1]; ++x) panel.push_back({x, K});
@@ -276,7 +220,7 @@ struct TileSym {
     // split tasks (split_max): scratch tiles are handed out per launch and come back two launches later (used in launch L, added and cleared in L + 1)
     // (sharded schedules, two_phase: a scratch tile handed out in launch L is added and cleared in L + 1 of the SAME phase - the deadline rule
     //  below never splits in a phase's last launch - so every scratch tile is zero again where the phases meet, i.e. at the all-reduce)
-    const int split = (!want_df && (n_elim < 0 || two_phase)) ? split_max : 0;
+    const int split = (n_elim < 0 || two_phase) ? split_max : 0;
     struct Due { int32_t tgt, scratch, col; bool diag; };
     std::vector<Due> due, due_next;
     std::vector<int32_t> free_ids, add_a((size_t)(split > 0 ? n_tiles : 0), 0), add_b(add_a);

@@ -99,7 +99,8 @@ int main(int argc, char** argv) {
   if (getenv("TS_SPLIT")) sym.split_max = atoi(getenv("TS_SPLIT"));   // several workgroups per target with many sources (scratch tiles)
   if (getenv("TS_SRC_CAP")) sym.src_cap = atoi(getenv("TS_SRC_CAP"));   // sources a target takes per launch (0: all behind their columns)
   const int nel = getenv("TS_NELIM") ? atoi(getenv("TS_NELIM")) : -1;   // two-phase schedule: must still solve the whole system
-  sym.analyse(nt, lower, true, nel < 0 ? -1 : std::min(nel, nt), nel >= 0, getenv("TS_SPLIT") == nullptr);   // (split tasks exclude the dataflow form)
+  if (getenv("TS_SPLIT") == nullptr) sym.split_max = 0;   // (the un-split schedule unless asked for)
+  sym.analyse(nt, lower, true, nel < 0 ? -1 : std::min(nel, nt), nel >= 0);
   // tile buffers
   std::vector<double> A(((size_t)sym.n_tiles + sym.n_scratch) * TT, 0.0), L((size_t)sym.n_tiles * TT, 0.0), Li((size_t)nt * TT), r(g), y(npad), w(npad), s(npad, 0.0), x(npad);
   r.resize((size_t)npad + (size_t)sym.n_scratch * TS, 0.0);   // scratch rhs segments of split tasks: columns nt ...

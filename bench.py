@@ -340,7 +340,7 @@ def main():
             "kernels": [{"name": s["name"], "launches": s["launches"], "total_ms": round(s["total_ms"], 3)} for s in stats],
             "kernels_note": "HIP-event time per launch group on the stream it ran on; up to three solves (the candidate GTSAM tries and the speculative "
                             "next ones) run concurrently on their own streams, so the rows add up to more than the timed region - the additive per-kernel "
-                            "table of the same run under rocprofv3 is profiles/r05_kernel_stats.txt, the share of discarded speculative solves is "
+                            "table of the same run under rocprofv3 is profiles/r06_kernel_stats.txt, the share of discarded speculative solves is "
                             "config.lambda_search",
         }
         if not args.no_cpu_baseline and world == 1:
@@ -380,7 +380,7 @@ def _schedule(ctx):
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/r02_pmc_hbm.txt: separate
     FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); None if absent."""
-    for name in ("r05_pmc_hbm.txt", "r04_pmc_hbm.txt", "r03_pmc_hbm.txt", "r02_pmc_hbm.txt", "r01_pmc_hbm.txt"):
+    for name in ("r06_pmc_hbm.txt", "r05_pmc_hbm.txt", "r04_pmc_hbm.txt", "r03_pmc_hbm.txt", "r02_pmc_hbm.txt", "r01_pmc_hbm.txt"):
         try:
             for ln in open(os.path.join(ROOT, "profiles", name)):
                 t = ln.split()

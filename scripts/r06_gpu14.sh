@@ -1,0 +1,14 @@
+bash scripts/r06_boxprobe.sh 2>&1 | grep -E "^==|it/s"
+export MASTER_ADDR=127.0.0.1
+timeout 1200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29713 bench.py --gpus 8 --backend gloo --steps 5 --warmup 2 > gpurun_out/r06_bench_gloo8_dryrun.json 2> gpurun_out/r06_bench_gloo8_dryrun.err
+echo rc $?
+python - <<'PY'
+import json
+try:
+    d=json.loads(open('gpurun_out/r06_bench_gloo8_dryrun.json').read().strip().splitlines()[-1])
+    c=d['config']
+    print('value', d['value'], 'ms/step', d['ms_per_step'], 'track_cut', c['track_cut_frames'], 'schedule', c['schedule'])
+    print('alt', {k:v for k,v in c['alt_track_cut'].items() if k!='note'})
+except Exception as e:
+    print('ERR', e)
+PY
